@@ -1,0 +1,112 @@
+/*
+ * pykmer_hip.h -- C-ABI of libpykmer_hip.so, the MI355X (gfx950) engine behind pykmer's two hot loops.
+ *
+ * The reference (sauloal/pykmer) is monolithic Python with no FFI; the boundary sits where it hands
+ * work to its hot loops.  Each entry point names the reference code it replaces
+ * (file:line into the reference repository).  Plain pointers and sizes only; the caller owns every
+ * host buffer; the library owns device memory.  All functions return PK_OK (0) or a negative
+ * PK_ERR_* code; pk_last_error() returns the message of the calling thread's last failure.
+ * Calls are blocking and may be issued concurrently for different devices.
+ */
+#ifndef PYKMER_HIP_H
+#define PYKMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PK_ABI_VERSION 1
+
+enum {
+    PK_OK = 0,
+    PK_ERR_ARG = -1,      /* even / non-positive / unsupported k, bad min/max count, null pointer */
+    PK_ERR_HIP = -2,      /* HIP runtime failure (no device, out of memory, launch error)        */
+    PK_ERR_RECS_CAP = -3, /* more records than recs_cap; *n_recs_out holds the number needed      */
+    PK_ERR_STATE = -4     /* handle used out of order                                            */
+};
+
+/* One FASTA record as the reference's parse_fasta yields it (indexer.py:45-99). The caller slices the
+ * header text out of its own buffer and drops records with n_valid_kmers == 0 to reproduce the
+ * `chromosomes` list (indexer.py:349-351). Offsets are relative to the first byte ever fed. */
+typedef struct pk_record {
+    uint64_t name_off;      /* first byte after '>'                                             */
+    uint64_t name_len;      /* header length after strip() (indexer.py:56,80)                   */
+    uint64_t seq_len;       /* stripped sequence characters, valid or not (indexer.py:77,93)    */
+    uint64_t n_valid_kmers; /* windows without a None (indexer.py:144)                          */
+} pk_record;
+
+int pk_version(void);
+int pk_last_error(char *buf, size_t n);
+int pk_device_count(void);
+
+/* ---- indexer: replaces gen_kmers + canonical min + process_kmers (indexer.py:130-160, 341, 162-297)
+ * and the parser that feeds them (indexer.py:45-99).  k must be odd, 1 <= k <= 17 (tools.py:165-167).
+ *
+ * fasta       uncompressed FASTA text (what gzip.open(...,'rt') would hand the reference)
+ * table_out   4^k bytes (host); receives table[a] = min(255, #canonical k-mers with value a): the
+ *             exact content of the reference's .kin file (tools.py:333-341, indexer.py:262)
+ * hist256_out nullable; 256 counters, hist256[v] = #{a : table[a] == v}.  Header.update_stats
+ *             (tools.py:246-263) follows from it: hist = hist256[1:], vals_sum = sum v*hist256[v] ...
+ */
+int pk_count_fasta(const uint8_t *fasta, uint64_t n_bytes, int k, uint8_t *table_out,
+                   uint64_t *num_kmers_out, uint64_t *total_bp_out, uint64_t hist256_out[256],
+                   pk_record *recs_out, uint64_t recs_cap, uint64_t *n_recs_out, int device);
+
+/* Streaming / device-resident form of the same path (inputs larger than host RAM, inputs that
+ * already live in HBM, repeated timing).  One indexer owns one 4^k table in HBM on one device. */
+typedef struct pk_indexer pk_indexer;
+int pk_indexer_create(pk_indexer **out, int k, int device);
+int pk_indexer_reset(pk_indexer *ix);                       /* zero the table, forget parser state  */
+/* Feed the next n_bytes of the FASTA text.  Chunks may split lines, records and k-mers anywhere.   */
+int pk_indexer_feed(pk_indexer *ix, const uint8_t *host_fasta, uint64_t n_bytes);
+/* Same, but the bytes already sit in device memory on the indexer's device (16-byte aligned).
+ * Work is enqueued on the indexer's stream; the call returns once the chunk's record count is known. */
+int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uint64_t n_bytes);
+/* Close the last record, clamp the table to u8 and build the 256-bin histogram, all in HBM.        */
+int pk_indexer_finish(pk_indexer *ix, uint64_t *num_kmers_out, uint64_t *total_bp_out,
+                      uint64_t hist256_out[256], uint64_t *n_recs_out);
+int pk_indexer_records(pk_indexer *ix, pk_record *recs_out, uint64_t recs_cap);
+int pk_indexer_table_to_host(pk_indexer *ix, uint8_t *table_out);
+/* Device pointer of the finished u8 table (valid until reset/destroy) -- lets a merge run on tables
+ * that never left HBM. */
+int pk_indexer_table_device(pk_indexer *ix, const void **dev_table_out);
+/* Seconds spent in the last feed_device..finish sequence per stage, measured with HIP events on the
+ * indexer's stream: [0] structure scans, [1] k-mer extract+count kernel, [2] clamp+histogram,
+ * [3] table zeroing, [4] count-kernel launches (as a double). */
+int pk_indexer_timings(pk_indexer *ix, double out[8]);
+void pk_indexer_destroy(pk_indexer *ix);
+
+/* ---- stats: replaces Header.update_stats (tools.py:246-263) on a host table of n bytes. */
+int pk_table_stats(const uint8_t *table, uint64_t n, uint64_t hist256_out[256], int device);
+
+/* ---- merger: replaces Header.calculate_distance (tools.py:439-493) for every pair of merger.merge
+ * (merger.py:139-176) in ONE pass over the N tables.
+ *
+ * tables      N host pointers to n-byte tables (n = 4^k, equal sizes: tools.py:444)
+ * min/max     validity window, 1 <= min, max <= 255 (merger.py:90-91)
+ * matrix_out  N*N*3 u64 row-major: [i][j] = (total_i, total_j, shared_ij) for i != j
+ *             (merger.py:175-176); the diagonal, which the reference leaves unassigned
+ *             (merger.py:136), is written as (0,0,0).
+ * devices     n_devices device ordinals; the address range is split evenly across them and the
+ *             partial matrices are summed on the host (single-process form).  The multi-process
+ *             RCCL form uses pk_gram_device_partial on each rank's slice.
+ */
+int pk_gram(const uint8_t *const *tables, int N, uint64_t n, int min_count, int max_count,
+            uint64_t *matrix_out, const int *devices, int n_devices);
+
+/* Device-resident slice form: dev_tables[i] points at n_slice bytes of table i in HBM on `device`.
+ * pair_out (host) receives N*N u64: [i][i] = total_i over the slice, [i][j] = shared_ij.  Summing
+ * pair_out over disjoint slices (ranks) and expanding with pk_gram_expand gives matrix_out.
+ * dev_pair_out (nullable, device, N*N u64) receives the same numbers in HBM for an RCCL all-reduce. */
+int pk_gram_device_partial(const void *const *dev_tables, int N, uint64_t n_slice, int min_count,
+                           int max_count, uint64_t *pair_out, void *dev_pair_out, int device,
+                           double *kernel_seconds_out);
+int pk_gram_expand(const uint64_t *pair, int N, uint64_t *matrix_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYKMER_HIP_H */

@@ -1,0 +1,98 @@
+"""oracle -- CPU restatement of the reference's hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+`kmer_oracle.c` (fast, streaming) is built with gcc into oracle/_build/; `pyoracle.py` is the
+literal pure-Python twin for small cases.  The reference is pure Python, so there is no
+oracle/_ref build: the pin is tests/golden/, written by oracle/gen_golden.py running the reference.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libpkoracle.so")
+_lib = None
+
+RECORD_DTYPE = np.dtype([("name_off", "<u8"), ("name_len", "<u8"), ("seq_len", "<u8"),
+                         ("n_valid_kmers", "<u8")])
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "kmer_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(_SO), exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", src, "-o", _SO])
+    return _SO
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        lib = ctypes.CDLL(build())
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        lib.pko_count_fasta.restype = ctypes.c_int
+        lib.pko_count_fasta.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p,
+                                        u64p, u64p, ctypes.c_void_p, ctypes.c_uint64, u64p]
+        lib.pko_table_stats.restype = ctypes.c_int
+        lib.pko_table_stats.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+        lib.pko_gram.restype = ctypes.c_int
+        lib.pko_gram.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                 ctypes.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def count_fasta(fasta, k: int, table: np.ndarray = None):
+    """Returns dict(table, num_kmers, total_bp, records[RECORD_DTYPE]).  `fasta`: bytes or u8 array."""
+    lib = _load()
+    buf = np.frombuffer(fasta, dtype=np.uint8) if isinstance(fasta, (bytes, bytearray)) else np.ascontiguousarray(fasta)
+    if table is None:
+        table = np.zeros(4 ** k, dtype=np.uint8)
+    nk, bp, nr = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    cap = 1024
+    while True:
+        recs = np.zeros(cap, dtype=RECORD_DTYPE)
+        scratch = table if cap == 1024 else np.zeros_like(table)
+        rc = lib.pko_count_fasta(buf.ctypes.data, buf.size, k, scratch.ctypes.data, ctypes.byref(nk),
+                                 ctypes.byref(bp), recs.ctypes.data, cap, ctypes.byref(nr))
+        if rc != 0:
+            raise ValueError(f"oracle rejected k={k}")
+        if nr.value <= cap:
+            break
+        cap = int(nr.value)                       # rare: re-run only to collect every record
+    return {"table": table, "num_kmers": int(nk.value), "total_bp": int(bp.value),
+            "records": recs[: nr.value].copy()}
+
+
+def chromosomes(fasta, records) -> list:
+    """[(name, seq_len)] for records with >= 1 valid k-mer (indexer.py:349-351)."""
+    raw = bytes(fasta) if not isinstance(fasta, (bytes, bytearray)) else fasta
+    out = []
+    for r in records:
+        if r["n_valid_kmers"]:
+            off, ln = int(r["name_off"]), int(r["name_len"])
+            out.append((raw[off:off + ln].decode("utf-8"), int(r["seq_len"])))
+    return out
+
+
+def table_stats(table: np.ndarray):
+    lib = _load()
+    t = np.ascontiguousarray(table, dtype=np.uint8)
+    hist = np.zeros(255, dtype=np.uint64)
+    vals = np.zeros(4, dtype=np.uint64)
+    lib.pko_table_stats(t.ctypes.data, t.size, hist.ctypes.data, vals.ctypes.data)
+    return hist, vals
+
+
+def gram(tables, min_count: int = 1, max_count: int = 255) -> np.ndarray:
+    lib = _load()
+    ts = [np.ascontiguousarray(t, dtype=np.uint8) for t in tables]
+    n = len(ts)
+    ptrs = (ctypes.c_void_p * n)(*[t.ctypes.data for t in ts])
+    m = np.zeros((n, n, 3), dtype=np.uint64)
+    rc = lib.pko_gram(ptrs, n, ts[0].size, min_count, max_count, m.ctypes.data)
+    if rc != 0:
+        raise ValueError("oracle rejected min/max count")
+    return m

@@ -1,0 +1,214 @@
+"""ctypes binding of libpykmer_hip.so (include/pykmer_hip.h).
+
+The engine has no CPU fallback: if the shared library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpykmer_hip.so")
+
+PK_OK, PK_ERR_ARG, PK_ERR_HIP, PK_ERR_RECS_CAP, PK_ERR_STATE = 0, -1, -2, -3, -4
+
+RECORD_DTYPE = np.dtype([("name_off", "<u8"), ("name_len", "<u8"), ("seq_len", "<u8"), ("n_valid_kmers", "<u8")])
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_SIGNATURES = {
+    "pk_version": (ctypes.c_int, []),
+    "pk_last_error": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
+    "pk_device_count": (ctypes.c_int, []),
+    "pk_count_fasta": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, _u64p, _u64p,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, _u64p, ctypes.c_int]),
+    "pk_indexer_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
+    "pk_indexer_reset": (ctypes.c_int, [ctypes.c_void_p]),
+    "pk_indexer_feed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
+    "pk_indexer_feed_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
+    "pk_indexer_finish": (ctypes.c_int, [ctypes.c_void_p, _u64p, _u64p, ctypes.c_void_p, _u64p]),
+    "pk_indexer_records": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
+    "pk_indexer_table_to_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "pk_indexer_table_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "pk_indexer_timings": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "pk_indexer_destroy": (None, [ctypes.c_void_p]),
+    "pk_table_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int]),
+    "pk_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "pk_gram_device_partial": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                               ctypes.POINTER(ctypes.c_double)]),
+    "pk_gram_expand": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class PkError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libpykmer_hip error {code}: {message}")
+        self.code = code
+
+
+def load():
+    """Loads the library (building nothing: run pykmer_amd.build or __graft_entry__.build first)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -m pykmer_amd.build` "
+                              "(there is no CPU fallback)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != PK_OK:
+        buf = ctypes.create_string_buffer(512)
+        load().pk_last_error(buf, 512)
+        msg = buf.value.decode("utf-8", "replace")
+        if rc == PK_ERR_ARG:
+            raise ValueError(msg)
+        raise PkError(rc, msg)
+
+
+def _as_u8(data) -> np.ndarray:
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(data, dtype=np.uint8)
+
+
+def device_count() -> int:
+    return load().pk_device_count()
+
+
+def _hist_out():
+    return np.zeros(256, dtype=np.uint64)
+
+
+class Indexer:
+    """One 4^k count table resident in HBM on one device (pk_indexer_*)."""
+
+    def __init__(self, k: int, device: int = 0):
+        self._h = ctypes.c_void_p()
+        self.k, self.device = k, device
+        _check(load().pk_indexer_create(ctypes.byref(self._h), k, device))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            load().pk_indexer_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def reset(self):
+        _check(load().pk_indexer_reset(self._h))
+
+    def feed(self, data):
+        buf = _as_u8(data)
+        _check(load().pk_indexer_feed(self._h, buf.ctypes.data, buf.size))
+
+    def feed_device(self, dev_ptr: int, n_bytes: int):
+        _check(load().pk_indexer_feed_device(self._h, ctypes.c_void_p(dev_ptr), n_bytes))
+
+    def finish(self):
+        nk, bp, nr = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+        hist = _hist_out()
+        _check(load().pk_indexer_finish(self._h, ctypes.byref(nk), ctypes.byref(bp), hist.ctypes.data, ctypes.byref(nr)))
+        return {"num_kmers": int(nk.value), "total_bp": int(bp.value), "hist256": hist, "n_records": int(nr.value)}
+
+    def records(self, n_records: int) -> np.ndarray:
+        recs = np.zeros(max(n_records, 1), dtype=RECORD_DTYPE)
+        _check(load().pk_indexer_records(self._h, recs.ctypes.data, recs.size))
+        return recs[:n_records]
+
+    def table_to_host(self, out: np.ndarray = None) -> np.ndarray:
+        if out is None:
+            out = np.empty(4 ** self.k, dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.size == 4 ** self.k and out.flags.c_contiguous
+        _check(load().pk_indexer_table_to_host(self._h, out.ctypes.data))
+        return out
+
+    def table_device_ptr(self) -> int:
+        p = ctypes.c_void_p()
+        _check(load().pk_indexer_table_device(self._h, ctypes.byref(p)))
+        return p.value
+
+    def timings(self) -> dict:
+        t = np.zeros(8, dtype=np.float64)
+        _check(load().pk_indexer_timings(self._h, t.ctypes.data))
+        return {"scan_s": t[0], "count_s": t[1], "finalize_s": t[2], "zero_s": t[3], "count_launches": int(t[4])}
+
+
+def count_fasta(data, k: int, device: int = 0, table_out: np.ndarray = None):
+    """pk_count_fasta: host FASTA text -> dict(table, num_kmers, total_bp, hist256, records)."""
+    buf = _as_u8(data)
+    if k <= 0 or k % 2 == 0 or k > 17:                      # let the library word the error (tools.py:165-167)
+        _check(load().pk_count_fasta(None, 0, k, None, None, None, None, None, 0, None, device))
+    table = table_out if table_out is not None else np.empty(4 ** k, dtype=np.uint8)
+    nk, bp, nr = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    hist = _hist_out()
+    cap = 4096
+    while True:
+        recs = np.zeros(cap, dtype=RECORD_DTYPE)
+        rc = load().pk_count_fasta(buf.ctypes.data, buf.size, k, table.ctypes.data, ctypes.byref(nk), ctypes.byref(bp),
+                                   hist.ctypes.data, recs.ctypes.data, cap, ctypes.byref(nr), device)
+        if rc == PK_ERR_RECS_CAP and nr.value > cap:
+            cap = int(nr.value)
+            continue
+        _check(rc)
+        break
+    return {"table": table, "num_kmers": int(nk.value), "total_bp": int(bp.value), "hist256": hist,
+            "records": recs[: nr.value].copy()}
+
+
+def table_stats(table: np.ndarray, device: int = 0) -> np.ndarray:
+    """pk_table_stats: 256-bin histogram of a host u8 table."""
+    t = _as_u8(table)
+    hist = _hist_out()
+    _check(load().pk_table_stats(t.ctypes.data, t.size, hist.ctypes.data, device))
+    return hist
+
+
+def gram(tables, min_count: int = 1, max_count: int = 255, devices=(0,)) -> np.ndarray:
+    """pk_gram on host tables -> (N,N,3) uint64 matrix (merger.py:136,175-176; zero diagonal)."""
+    ts = [_as_u8(t) for t in tables]
+    n = ts[0].size
+    if any(t.size != n for t in ts):
+        raise AssertionError("tables differ in size (tools.py:444)")
+    N = len(ts)
+    ptrs = (ctypes.c_void_p * N)(*[t.ctypes.data for t in ts])
+    devs = (ctypes.c_int * len(devices))(*devices)
+    m = np.zeros((N, N, 3), dtype=np.uint64)
+    _check(load().pk_gram(ptrs, N, n, min_count, max_count, m.ctypes.data, devs, len(devices)))
+    return m
+
+
+def gram_device_partial(dev_ptrs, n_slice: int, min_count: int = 1, max_count: int = 255, device: int = 0,
+                        dev_pair_out: int = None):
+    """pk_gram_device_partial on device-resident slices -> (pair[N,N] uint64, kernel_seconds)."""
+    N = len(dev_ptrs)
+    ptrs = (ctypes.c_void_p * N)(*dev_ptrs)
+    pair = np.zeros((N, N), dtype=np.uint64)
+    secs = ctypes.c_double(0)
+    _check(load().pk_gram_device_partial(ptrs, N, n_slice, min_count, max_count, pair.ctypes.data,
+                                         ctypes.c_void_p(dev_pair_out) if dev_pair_out else None, device,
+                                         ctypes.byref(secs)))
+    return pair, secs.value
+
+
+def gram_expand(pair: np.ndarray) -> np.ndarray:
+    p = np.ascontiguousarray(pair, dtype=np.uint64)
+    N = p.shape[0]
+    m = np.zeros((N, N, 3), dtype=np.uint64)
+    _check(load().pk_gram_expand(p.ctypes.data, N, m.ctypes.data))
+    return m

@@ -1,0 +1,245 @@
+// fasta_fsm.h -- device-side FASTA state machine shared by the structure-scan and k-mer kernels.
+//
+// The reference parses FASTA line by line on the host (indexer.py:45-99): strip() each line, skip
+// empty ones, a line starting with '>' opens a record, every other line is sequence; k-mers run
+// across line breaks inside a record and never across records; characters outside ACGTacgt map to
+// None and void every window that contains them (indexer.py:36-41,144).
+//
+// On the GPU the byte stream is cut into fixed 64-byte lane pieces (256 lanes = one 16 KiB chunk
+// per workgroup).  A piece can start anywhere -- mid-line, mid-header, mid-k-mer -- so each piece
+// is first reduced to a small *summary* (how it transforms the parser state), summaries are
+// combined with an associative compose() in prefix scans (lane -> wave -> workgroup -> grid), and
+// only then does every lane re-walk its piece from its now exact start state.  Two levels:
+//   L1  line state: are we at line start / inside a header line / inside a sequence line
+//   L2  record index, pending (not yet classified) whitespace, and the last <= k-1 valid bases
+// This is exact for any input: unwrapped 100 Mbp lines, CRLF, blank lines, interior blanks ...
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pk {
+
+constexpr int WG = 256;            // threads per workgroup
+constexpr int PIECE = 64;          // bytes walked by one lane
+constexpr int CHUNK = WG * PIECE;  // bytes per workgroup (16 KiB)
+constexpr int LDS_STRIDE = 80;     // lane piece stride in LDS: 20 banks -> conflict-free ds_read_b128
+
+enum : uint32_t { LS_START = 0, LS_HEADER = 1, LS_SEQ = 2 };
+
+__device__ __forceinline__ bool is_term(uint32_t c) { return c == 10u || c == 13u; }
+// str.strip() whitespace, ASCII subset (indexer.py:56): \t \n \v \f \r, FS GS RS US, space
+__device__ __forceinline__ bool is_ws(uint32_t c) { return c == 32u || (c - 9u) <= 4u || (c - 28u) <= 3u; }
+// CONV (indexer.py:36-41): 0..3 for ACGT/acgt, 4 otherwise
+__device__ __forceinline__ uint32_t base_code(uint32_t c) {
+    uint32_t u = c | 0x20u;
+    uint32_t code = (u == 'a') ? 0u : (u == 'c') ? 1u : (u == 'g') ? 2u : (u == 't') ? 3u : 4u;
+    return code;
+}
+
+// ---------------------------------------------------------------- L1: line state -------------
+// Encoding: 0 = identity; else bit3 set, bit0 = piece contains a line terminator, bits1-2 = kind:
+// the line state at the end of the piece if it has a terminator, otherwise what LS_START becomes
+// (LS_HEADER and LS_SEQ pass through a terminator-free piece unchanged).
+typedef uint32_t L1;
+__device__ __forceinline__ L1 l1_make(bool has_term, uint32_t kind) { return 8u | (has_term ? 1u : 0u) | (kind << 1); }
+__device__ __forceinline__ L1 l1_state(uint32_t ls) { return l1_make(true, ls); }
+__device__ __forceinline__ uint32_t l1_kind(L1 a) { return (a >> 1) & 3u; }
+__device__ __forceinline__ L1 l1_compose(L1 a, L1 b) {   // a first, then b
+    if (!b) return a;
+    if (!a) return b;
+    uint32_t ak = l1_kind(a), bk = l1_kind(b);
+    uint32_t kind = (b & 1u) ? bk : (ak == LS_START ? bk : ak);
+    return 8u | ((a | b) & 1u) | (kind << 1);
+}
+
+// ---------------------------------------------------------------- L2: record / run state -----
+// flags: bit0 non-identity, bit1 p_reset (piece holds an event that zeroes pending whitespace),
+// bit2 F (piece starts in a sequence line with a non-blank character: breaks the run iff the
+// incoming pending-whitespace count is > 0), bit3 brk (run broken inside, or >= k-1 valid bases:
+// incoming bases irrelevant), bits 8-15 len (valid bases after the last break, capped at k-1).
+struct L2 {
+    uint32_t flags;
+    uint32_t bits;    // those `len` bases, 2 bits each, newest lowest
+    uint32_t rec;     // record headers opened
+    uint64_t p_tail;  // pending whitespace at the end (since the last reset, or since the start)
+};
+constexpr uint32_t F_NONID = 1u, F_PRESET = 2u, F_FRONT = 4u, F_BRK = 8u;
+
+__device__ __forceinline__ uint32_t l2_len(const L2 &a) { return (a.flags >> 8) & 0xffu; }
+__device__ __forceinline__ uint32_t bases_mask(uint32_t nb) { return nb >= 16u ? 0xffffffffu : ((1u << (2u * nb)) - 1u); }
+__device__ __forceinline__ L2 l2_identity() { L2 z; z.flags = 0; z.bits = 0; z.rec = 0; z.p_tail = 0; return z; }
+
+// A concrete parser state is the summary "whatever came before, the state is now this".
+__device__ __forceinline__ L2 l2_state(uint64_t pending, uint32_t run, uint32_t bases, uint32_t rec) {
+    L2 s; s.flags = F_NONID | F_PRESET | F_BRK | (run << 8); s.bits = bases; s.rec = rec; s.p_tail = pending; return s;
+}
+
+__device__ __forceinline__ L2 l2_compose(const L2 &a, const L2 &b, uint32_t km1) {   // a first, then b
+    if (!(b.flags & F_NONID)) return a;
+    if (!(a.flags & F_NONID)) return b;
+    L2 c;
+    c.rec = a.rec + b.rec;
+    c.p_tail = (b.flags & F_PRESET) ? b.p_tail : a.p_tail + b.p_tail;
+    uint32_t f = F_NONID | ((a.flags | b.flags) & F_PRESET) | (a.flags & F_FRONT);
+    // b's first character closes a's trailing whitespace as *interior* whitespace -> run broken.
+    // (If a has no reset and p_tail == 0 it holds no sequence-line event, so b cannot carry F.)
+    bool front_break = (b.flags & F_FRONT) && (a.p_tail > 0);
+    uint32_t blen = l2_len(b), alen = l2_len(a);
+    if ((b.flags & F_BRK) || front_break || blen >= km1) {
+        f |= F_BRK | (blen << 8);
+        c.bits = b.bits;
+    } else {
+        uint32_t tot = alen + blen;
+        if (tot > km1) tot = km1;
+        f |= (a.flags & F_BRK) | (tot << 8);
+        c.bits = ((a.bits << (2u * blen)) | b.bits) & bases_mask(km1);
+    }
+    c.flags = f;
+    return c;
+}
+
+// ---- wave / workgroup exclusive scans (64-wide wavefronts, non-commutative operator) ----------
+__device__ __forceinline__ L1 wave_incl_scan_l1(L1 v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        L1 o = __shfl_up(v, d, 64);
+        if (lane >= d) v = l1_compose(o, v);
+    }
+    return v;
+}
+__device__ __forceinline__ L2 shfl_up_l2(const L2 &v, int d) {
+    L2 o;
+    o.flags = __shfl_up(v.flags, d, 64);
+    o.bits = __shfl_up(v.bits, d, 64);
+    o.rec = __shfl_up(v.rec, d, 64);
+    o.p_tail = __shfl_up((unsigned long long)v.p_tail, d, 64);
+    return o;
+}
+__device__ __forceinline__ L2 wave_incl_scan_l2(L2 v, int lane, uint32_t km1) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        L2 o = shfl_up_l2(v, d);
+        if (lane >= d) v = l2_compose(o, v, km1);
+    }
+    return v;
+}
+
+// Exclusive scan over the 256 lanes of a workgroup, seeded with `seed` (the state before lane 0).
+// Returns this lane's start state; *total (valid in every lane) = seed . lane0 . ... . lane255.
+__device__ __forceinline__ L1 wg_excl_scan_l1(L1 mine, L1 seed, L1 *sh /*[4]*/, L1 *total) {
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    L1 inc = wave_incl_scan_l1(mine, lane);
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    L1 pre = seed;
+    for (int i = 0; i < w; i++) pre = l1_compose(pre, sh[i]);
+    L1 tot = pre;
+    for (int i = w; i < WG / 64; i++) tot = l1_compose(tot, sh[i]);
+    *total = tot;
+    L1 up = __shfl_up(inc, 1, 64);
+    L1 res = (lane == 0) ? pre : l1_compose(pre, up);
+    __syncthreads();
+    return res;
+}
+__device__ __forceinline__ L2 wg_excl_scan_l2(const L2 &mine, const L2 &seed, L2 *sh /*[4]*/, L2 *total, uint32_t km1) {
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    L2 inc = wave_incl_scan_l2(mine, lane, km1);
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    L2 pre = seed;
+    for (int i = 0; i < w; i++) pre = l2_compose(pre, sh[i], km1);
+    L2 tot = pre;
+    for (int i = w; i < WG / 64; i++) tot = l2_compose(tot, sh[i], km1);
+    *total = tot;
+    L2 up = shfl_up_l2(inc, 1);
+    L2 res = (lane == 0) ? pre : l2_compose(pre, up, km1);
+    __syncthreads();
+    return res;
+}
+
+// ---- staging: one 16 KiB chunk, coalesced 16 B per lane, into padded LDS pieces ----------------
+// fasta must be 16-byte aligned.  Bytes at or beyond n_bytes are never read from memory.
+__device__ __forceinline__ void stage_chunk(const uint8_t *__restrict__ fasta, uint64_t chunk_base, uint64_t n_bytes,
+                                            uint8_t *lds) {
+#pragma unroll
+    for (int i = 0; i < CHUNK / (WG * 16); i++) {
+        uint32_t p = i * WG + threadIdx.x;
+        uint64_t g = chunk_base + (uint64_t)p * 16u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g + 16u <= n_bytes) {
+            v = *reinterpret_cast<const uint4 *>(fasta + g);
+        } else if (g < n_bytes) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (uint32_t j = 0; j < (uint32_t)(n_bytes - g); j++) w[j >> 2] |= (uint32_t)fasta[g + j] << (8u * (j & 3u));
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        uint32_t bo = p * 16u;
+        *reinterpret_cast<uint4 *>(lds + (bo / PIECE) * LDS_STRIDE + (bo % PIECE)) = v;
+    }
+}
+__device__ __forceinline__ uint32_t piece_len(uint64_t chunk_base, uint64_t n_bytes) {
+    uint64_t start = chunk_base + (uint64_t)threadIdx.x * PIECE;
+    if (start >= n_bytes) return 0;
+    uint64_t left = n_bytes - start;
+    return left < (uint64_t)PIECE ? (uint32_t)left : (uint32_t)PIECE;
+}
+
+// Walks the lane's piece in LDS calling f(index, byte) for each of its nb bytes.
+template <class Fn>
+__device__ __forceinline__ void for_each_byte(const uint8_t *lds, uint32_t nb, Fn &&f) {
+    const uint8_t *mine = lds + threadIdx.x * LDS_STRIDE;
+#pragma unroll
+    for (int q = 0; q < PIECE / 16; q++) {
+        if ((uint32_t)(q * 16) >= nb) break;
+        uint4 v = *reinterpret_cast<const uint4 *>(mine + q * 16);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            uint32_t idx = q * 16 + j;
+            if (idx < nb) f(idx, (w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+        }
+    }
+}
+
+// L1 summary of the lane's piece.
+__device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb) {
+    if (nb == 0) return 0;
+    uint32_t st = LS_START;
+    bool ht = false;
+    for_each_byte(lds, nb, [&](uint32_t, uint32_t c) {
+        if (is_term(c)) { st = LS_START; ht = true; }
+        else if (st == LS_START && !is_ws(c)) st = (c == '>') ? LS_HEADER : LS_SEQ;
+    });
+    return l1_make(ht, st);
+}
+
+// L2 summary of the lane's piece, given its exact incoming line state.
+__device__ __forceinline__ L2 piece_l2(const uint8_t *lds, uint32_t nb, uint32_t ls_in, uint32_t km1) {
+    if (nb == 0) return l2_identity();
+    uint32_t ls = ls_in, flags = F_NONID, len = 0, bits = 0, rec = 0;
+    uint32_t pt = 0;
+    const uint32_t bm = bases_mask(km1);
+    for_each_byte(lds, nb, [&](uint32_t i, uint32_t c) {
+        if (is_term(c)) { ls = LS_START; flags |= F_PRESET; pt = 0; return; }
+        bool ws = is_ws(c);
+        if (ls == LS_START) {
+            if (ws) return;
+            if (c == '>') { ls = LS_HEADER; rec++; flags |= F_BRK; len = 0; bits = 0; return; }
+            ls = LS_SEQ;
+        } else if (ls == LS_HEADER) {
+            return;
+        } else if (ws) { pt++; return; }
+        // sequence character
+        if (i == 0 && ls_in == LS_SEQ) flags |= F_FRONT;
+        if (pt) { flags |= F_BRK; len = 0; bits = 0; }     // whitespace inside the piece became interior
+        flags |= F_PRESET; pt = 0;
+        uint32_t code = base_code(c);
+        if (code < 4u) { bits = ((bits << 2) | code) & bm; if (len < km1) len++; }
+        else { flags |= F_BRK; len = 0; bits = 0; }
+    });
+    if (len >= km1) flags |= F_BRK;
+    L2 s; s.flags = flags | (len << 8); s.bits = bits; s.rec = rec; s.p_tail = pt;
+    return s;
+}
+
+}  // namespace pk

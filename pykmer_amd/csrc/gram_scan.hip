@@ -1,0 +1,263 @@
+// gram_scan.hip -- merger kernel for gfx950: all-pairs shared-k-mer tallies over N dense tables in
+// ONE streaming pass.
+//
+// Replaces Header.calculate_distance (tools.py:439-493), which the reference runs once per PAIR
+// (merger.py:139-153) re-reading both 4^k-byte tables each time: N(N-1) table reads.  Here every
+// table byte is read from HBM exactly once: each lane turns 32 consecutive addresses of a table
+// into one 32-bit validity mask ((count >= min) & (count <= max), tools.py:473-474; SWAR on
+// dwords), and pair tallies are v_and + v_bcnt accumulates on those masks:
+//   pair[i][i] = sum popc(m_i)          = total_i   (tools.py:480-481)
+//   pair[i][j] = sum popc(m_i & m_j)    = shared_ij (tools.py:475,482)
+// The kernel is HBM-bound (N * 4^k bytes); MFMA is deliberately not used.
+//
+// Two shapes:
+//   k_gram_reg<NT>  N <= 16: all N masks and all N(N+1)/2 accumulators in registers, no LDS, no barrier
+//   k_gram_blk      any N <= 128: masks of a 256-word tile staged in LDS, 8x8 table "pair blocks"
+//                   spread over the waves of the workgroup, accumulators (2-3 x 64) in registers
+#include "pk_kernels.h"
+
+namespace pk {
+
+struct ValidParams {
+    uint32_t lo_rep;   // (min & 0x7f) replicated to 4 bytes
+    uint32_t lo_hi;    // min >= 128
+    uint32_t up_rep;   // ((max+1) & 0x7f) replicated
+    uint32_t up_hi;    // max+1 >= 128
+    uint32_t has_up;   // max < 255
+};
+
+constexpr uint32_t H4 = 0x80808080u, L4 = 0x7f7f7f7fu;
+
+// bit 7 of each byte set iff that byte is a valid count
+template <bool FAST>
+__device__ __forceinline__ uint32_t valid_bits(uint32_t x, const ValidParams &p) {
+    if (FAST) return (((x & L4) + L4) | x) & H4;               // min=1, max=255: byte != 0
+    uint32_t xl = x & L4, xh = x & H4;
+    uint32_t gl = ((xl | H4) - p.lo_rep) & H4;                  // low 7 bits >= low 7 bits of min
+    uint32_t ge = p.lo_hi ? (xh & gl) : (xh | gl);
+    if (p.has_up) {
+        uint32_t ul = ((xl | H4) - p.up_rep) & H4;
+        uint32_t gu = p.up_hi ? (xh & ul) : (xh | ul);          // byte >= max+1
+        ge &= ~gu;
+    }
+    return ge;
+}
+
+// 32 table bytes (8 dwords) -> one 32-bit mask.  Bit layout is the same for every table, which is
+// all the tallies need.
+template <bool FAST>
+__device__ __forceinline__ uint32_t mask32(const uint4 &a, const uint4 &b, const ValidParams &p) {
+    uint32_t m = valid_bits<FAST>(a.x, p) >> 7;
+    m |= valid_bits<FAST>(a.y, p) >> 6;
+    m |= valid_bits<FAST>(a.z, p) >> 5;
+    m |= valid_bits<FAST>(a.w, p) >> 4;
+    m |= valid_bits<FAST>(b.x, p) >> 3;
+    m |= valid_bits<FAST>(b.y, p) >> 2;
+    m |= valid_bits<FAST>(b.z, p) >> 1;
+    m |= valid_bits<FAST>(b.w, p);
+    return m;
+}
+
+// guarded load of 32 bytes starting at word w (bytes beyond n read as 0 = never valid)
+__device__ __forceinline__ void load_word(const uint8_t *t, uint64_t w, uint64_t n, uint4 &a, uint4 &b) {
+    uint64_t off = w * 32u;
+    if (off + 32u <= n) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(t + off);
+        a = p[0]; b = p[1];
+    } else {
+        uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint64_t i = off; i < n; i++) v[(i - off) >> 2] |= (uint32_t)t[i] << (8u * ((i - off) & 3u));
+        a = make_uint4(v[0], v[1], v[2], v[3]); b = make_uint4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ N <= 16: registers only ----
+template <int NT, bool FAST>
+__global__ __launch_bounds__(256) void k_gram_reg(const uint8_t *const *__restrict__ tables, uint64_t n, ValidParams vp,
+                                                  unsigned long long *__restrict__ pair) {
+    const uint8_t *tp[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++) tp[i] = tables[i];
+    uint32_t acc[NT * (NT + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < NT * (NT + 1) / 2; i++) acc[i] = 0;
+    const uint64_t n_words = (n + 31u) / 32u;
+    for (uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * 256u) {
+        uint32_t m[NT];
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            uint4 a, b;
+            load_word(tp[i], w, n, a, b);
+            m[i] = mask32<FAST>(a, b, vp);
+        }
+        int idx = 0;
+#pragma unroll
+        for (int i = 0; i < NT; i++)
+#pragma unroll
+            for (int j = i; j < NT; j++) acc[idx++] += __builtin_popcount(m[i] & m[j]);
+    }
+    int idx = 0;
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = i; j < NT; j++) {
+            uint32_t s = wave_sum(acc[idx++]);
+            if ((threadIdx.x & 63) == 0 && s) atomicAdd(&pair[i * NT + j], (unsigned long long)s);
+        }
+}
+
+// ------------------------------------------------------------------ any N: LDS-tiled ------------
+constexpr int BLK = 8;            // tables per block
+constexpr int TILE_WORDS = 256;   // 32-address words per tile (8 KiB of each table)
+constexpr int MAX_PB = 24;        // pair blocks per launch: 8 waves x 3 slots
+
+struct PairBlocks {               // which 8x8 table-block pairs this launch tallies
+    int n;
+    int8_t bi[MAX_PB], bj[MAX_PB];
+};
+
+template <int SLOTS, bool FAST>
+__global__ __launch_bounds__(512) void k_gram_blk(const uint8_t *const *__restrict__ tables, int N, uint64_t n, ValidParams vp,
+                                                  PairBlocks pbs, unsigned long long *__restrict__ pair) {
+    extern __shared__ uint32_t masks[];                 // [NB*BLK][TILE_WORDS]
+    const int NB = (N + BLK - 1) / BLK;
+    const int nthreads = blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int bi[SLOTS], bj[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+        int pb = wave * SLOTS + s;
+        bi[s] = pb < pbs.n ? pbs.bi[pb] : -1;
+        bj[s] = pb < pbs.n ? pbs.bj[pb] : -1;
+    }
+    uint32_t acc[SLOTS][BLK][BLK];
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++)
+#pragma unroll
+        for (int i = 0; i < BLK; i++)
+#pragma unroll
+            for (int j = 0; j < BLK; j++) acc[s][i][j] = 0;
+
+    const uint64_t n_words = (n + 31u) / 32u;
+    const uint64_t n_tiles = (n_words + TILE_WORDS - 1) / TILE_WORDS;
+    const int items = NB * BLK * TILE_WORDS;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t w0 = tile * TILE_WORDS;
+        // phase 1: every (table, word) of the tile -> mask in LDS; consecutive lanes, consecutive words
+        for (int q = threadIdx.x; q < items; q += nthreads) {
+            int t = q / TILE_WORDS, w = q % TILE_WORDS;
+            uint32_t m = 0;
+            if (t < N && w0 + w < n_words) {
+                uint4 a, b;
+                load_word(tables[t], w0 + w, n, a, b);
+                m = mask32<FAST>(a, b, vp);
+            }
+            masks[q] = m;
+        }
+        __syncthreads();
+        // phase 2: each wave tallies its 8x8 pair blocks over the tile's words
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            if (bi[s] < 0) continue;
+            const uint32_t *mi = masks + bi[s] * BLK * TILE_WORDS, *mj = masks + bj[s] * BLK * TILE_WORDS;
+#pragma unroll
+            for (int r = 0; r < TILE_WORDS / 64; r++) {
+                uint32_t a[BLK], b[BLK];
+#pragma unroll
+                for (int i = 0; i < BLK; i++) { a[i] = mi[i * TILE_WORDS + r * 64 + lane]; b[i] = mj[i * TILE_WORDS + r * 64 + lane]; }
+#pragma unroll
+                for (int i = 0; i < BLK; i++)
+#pragma unroll
+                    for (int j = 0; j < BLK; j++) acc[s][i][j] += __builtin_popcount(a[i] & b[j]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+        if (bi[s] < 0) continue;
+#pragma unroll
+        for (int i = 0; i < BLK; i++)
+#pragma unroll
+            for (int j = 0; j < BLK; j++) {
+                int gi = bi[s] * BLK + i, gj = bj[s] * BLK + j;
+                uint32_t v = wave_sum(acc[s][i][j]);
+                if (lane == 0 && v && gi < N && gj < N && gi <= gj) atomicAdd(&pair[gi * N + gj], (unsigned long long)v);
+            }
+    }
+}
+
+// ------------------------------------------------------------------ launcher --------------------
+template <int NT>
+static void launch_reg(const uint8_t *const *t, uint64_t n, const ValidParams &vp, bool fast, unsigned long long *pair, uint32_t grid,
+                       hipStream_t s) {
+    if (fast) hipLaunchKernelGGL((k_gram_reg<NT, true>), dim3(grid), dim3(256), 0, s, t, n, vp, pair);
+    else hipLaunchKernelGGL((k_gram_reg<NT, false>), dim3(grid), dim3(256), 0, s, t, n, vp, pair);
+}
+
+int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int min_count, int max_count,
+                unsigned long long *dev_pair, hipStream_t s) {
+    if (N < 1 || N > 128) return -1;                      // 128 tables x 256 words x 4 B = 128 KiB of LDS
+    if (hipMemsetAsync(dev_pair, 0, sizeof(unsigned long long) * (size_t)N * N, s) != hipSuccess) return -2;
+    if (n_slice == 0) return 0;
+    ValidParams vp;
+    vp.lo_rep = (uint32_t)(min_count & 0x7f) * 0x01010101u;
+    vp.lo_hi = min_count >= 128;
+    vp.has_up = max_count < 255;
+    vp.up_rep = (uint32_t)((max_count + 1) & 0x7f) * 0x01010101u;
+    vp.up_hi = (max_count + 1) >= 128;
+    const bool fast = (min_count == 1 && max_count == 255);
+    const uint64_t n_words = (n_slice + 31u) / 32u;
+    if (N <= 16) {
+        uint64_t g = (n_words + 255u) / 256u;
+        uint32_t grid = (uint32_t)(g < 256u * 8u ? g : 256u * 8u);
+        switch (N) {
+#define PK_CASE(X) case X: launch_reg<X>(dev_tables, n_slice, vp, fast, dev_pair, grid, s); break;
+            PK_CASE(1) PK_CASE(2) PK_CASE(3) PK_CASE(4) PK_CASE(5) PK_CASE(6) PK_CASE(7) PK_CASE(8)
+            PK_CASE(9) PK_CASE(10) PK_CASE(11) PK_CASE(12) PK_CASE(13) PK_CASE(14) PK_CASE(15) PK_CASE(16)
+#undef PK_CASE
+        }
+    } else {
+        // 8x8 pair blocks, at most MAX_PB per launch; every launch streams all N tables once
+        // (N <= 48: one launch; beyond that the extra launches re-read the tables).
+        const int NB = (N + BLK - 1) / BLK;
+        const size_t lds = (size_t)NB * BLK * TILE_WORDS * sizeof(uint32_t);
+        uint64_t n_tiles = (n_words + TILE_WORDS - 1) / TILE_WORDS;
+        uint32_t grid = (uint32_t)(n_tiles < 512u ? n_tiles : 512u);
+        PairBlocks pbs;
+        pbs.n = 0;
+        auto flush = [&]() {
+            if (!pbs.n) return;
+            const int slots = pbs.n <= 16 ? 2 : 3;
+            const int waves = (pbs.n + slots - 1) / slots;
+            if (lds > 64u * 1024u) {                       // opt in to more than 64 KiB of dynamic LDS
+                hipFuncSetAttribute((const void *)k_gram_blk<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            }
+            if (slots == 2) {
+                if (fast) hipLaunchKernelGGL((k_gram_blk<2, true>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+                else hipLaunchKernelGGL((k_gram_blk<2, false>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+            } else {
+                if (fast) hipLaunchKernelGGL((k_gram_blk<3, true>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+                else hipLaunchKernelGGL((k_gram_blk<3, false>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+            }
+            pbs.n = 0;
+        };
+        for (int a = 0; a < NB; a++)
+            for (int b = a; b < NB; b++) {
+                pbs.bi[pbs.n] = (int8_t)a; pbs.bj[pbs.n] = (int8_t)b; pbs.n++;
+                if (pbs.n == MAX_PB) flush();
+            }
+        flush();
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace pk

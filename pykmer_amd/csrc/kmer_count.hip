@@ -1,0 +1,299 @@
+// kmer_count.hip -- indexer kernels for gfx950: FASTA structure scans, the fused
+// 2-bit-encode / rolling canonical k-mer / table-increment kernel, and the clamp+histogram pass.
+//
+// Replaces, in the reference: parse_fasta (indexer.py:45-99), gen_kmers (indexer.py:130-160), the
+// canonical min (indexer.py:341), process_kmers (indexer.py:162-297) and Header.update_stats
+// (tools.py:246-263).  See fasta_fsm.h for how the sequential parser is made data-parallel.
+//
+// Table update, version 1 ("direct"): the 4^k counters live in HBM as u32 (4 GiB at k=15, 64 GiB at
+// k=17 -- both resident in 288 GB), every lane run-length-merges consecutive identical canonical
+// k-mers (homopolymers, (AT)n: the contended buckets) and issues one no-return
+// global_atomic_add_u32 per run; k_finalize then clamps to u8, which is exact because the reference
+// only ever keeps min(255, count) (indexer.py:239,262).
+#include "fasta_fsm.h"
+#include "pk_kernels.h"
+
+namespace pk {
+
+// ------------------------------------------------------------------ per-chunk summaries --------
+__global__ __launch_bounds__(WG) void k_chunk_l1(const uint8_t *__restrict__ fasta, uint64_t n_bytes, L1 *__restrict__ chunk_l1) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[WG * LDS_STRIDE];
+    __shared__ L1 sh[WG / 64];
+    uint64_t base = (uint64_t)blockIdx.x * CHUNK;
+    stage_chunk(fasta, base, n_bytes, lds);
+    __syncthreads();
+    L1 mine = piece_l1(lds, piece_len(base, n_bytes));
+    L1 total;
+    wg_excl_scan_l1(mine, 0u, sh, &total);
+    if (threadIdx.x == 0) chunk_l1[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(WG) void k_chunk_l2(const uint8_t *__restrict__ fasta, uint64_t n_bytes,
+                                                 const L1 *__restrict__ chunk_l1_state, L2 *__restrict__ chunk_l2, uint32_t km1) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[WG * LDS_STRIDE];
+    __shared__ L1 sh1[WG / 64];
+    __shared__ L2 sh2[WG / 64];
+    uint64_t base = (uint64_t)blockIdx.x * CHUNK;
+    stage_chunk(fasta, base, n_bytes, lds);
+    __syncthreads();
+    uint32_t nb = piece_len(base, n_bytes);
+    L1 tot1;
+    L1 st1 = wg_excl_scan_l1(piece_l1(lds, nb), chunk_l1_state[blockIdx.x], sh1, &tot1);
+    L2 mine = piece_l2(lds, nb, l1_kind(st1), km1);
+    L2 total;
+    wg_excl_scan_l2(mine, l2_identity(), sh2, &total, km1);
+    if (threadIdx.x == 0) chunk_l2[blockIdx.x] = total;
+}
+
+// ------------------------------------------------------------------ grid-level scans -----------
+// One workgroup of 1024 threads; n is at most a few hundred thousand chunk summaries.
+constexpr int SCAN_T = 1024;
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_l1(const L1 *__restrict__ in, uint32_t n, Carry *carry, L1 *__restrict__ out_state) {
+    __shared__ L1 sh[SCAN_T / 64];
+    uint32_t per = (n + SCAN_T - 1) / SCAN_T, lo = threadIdx.x * per, hi = min(lo + per, n);
+    L1 acc = 0;
+    for (uint32_t i = lo; i < hi; i++) acc = l1_compose(acc, in[i]);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    L1 inc = wave_incl_scan_l1(acc, lane);
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    L1 pre = carry->l1;
+    for (int i = 0; i < w; i++) pre = l1_compose(pre, sh[i]);
+    L1 up = __shfl_up(inc, 1, 64);
+    L1 run = (lane == 0) ? pre : l1_compose(pre, up);
+    L1 start = run;
+    for (uint32_t i = lo; i < hi; i++) { out_state[i] = run; run = l1_compose(run, in[i]); }
+    __syncthreads();
+    if (threadIdx.x == SCAN_T - 1) carry->l1 = l1_compose(start, acc);
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_l2(const L2 *__restrict__ in, uint32_t n, Carry *carry, L2 *__restrict__ out_state, uint32_t km1) {
+    __shared__ L2 sh[SCAN_T / 64];
+    uint32_t per = (n + SCAN_T - 1) / SCAN_T, lo = threadIdx.x * per, hi = min(lo + per, n);
+    L2 acc = l2_identity();
+    for (uint32_t i = lo; i < hi; i++) acc = l2_compose(acc, in[i], km1);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    L2 inc = wave_incl_scan_l2(acc, lane, km1);
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    L2 pre = carry->l2;
+    for (int i = 0; i < w; i++) pre = l2_compose(pre, sh[i], km1);
+    L2 up = shfl_up_l2(inc, 1);
+    L2 run = (lane == 0) ? pre : l2_compose(pre, up, km1);
+    L2 start = run;
+    for (uint32_t i = lo; i < hi; i++) { out_state[i] = run; run = l2_compose(run, in[i], km1); }
+    __syncthreads();
+    if (threadIdx.x == SCAN_T - 1) { carry->l2 = l2_compose(start, acc, km1); carry->n_recs = carry->l2.rec; }
+}
+
+// ------------------------------------------------------------------ k-mer walk -----------------
+// Sink for table update v1: u32 counters in HBM, per-lane run-length merge, no-return atomics.
+struct DirectSink {
+    uint32_t *table;
+    uint64_t last;
+    uint32_t cnt;
+    __device__ __forceinline__ void init(uint32_t *t) { table = t; last = 0; cnt = 0; }
+    __device__ __forceinline__ void emit(uint64_t a) {
+        if (cnt && a == last) { cnt++; return; }
+        if (cnt) __hip_atomic_fetch_add(table + last, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = a; cnt = 1;
+    }
+    __device__ __forceinline__ void flush() {
+        if (cnt) __hip_atomic_fetch_add(table + last, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cnt = 0;
+    }
+};
+
+template <typename KT>
+__global__ __launch_bounds__(WG) void k_count(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
+                                              const L1 *__restrict__ chunk_l1_state, const L2 *__restrict__ chunk_l2_state,
+                                              uint32_t k, uint32_t *__restrict__ table32, DevRec *__restrict__ recs,
+                                              uint64_t recs_cap, Carry *carry) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[WG * LDS_STRIDE];
+    __shared__ L1 sh1[WG / 64];
+    __shared__ L2 sh2[WG / 64];
+    const uint32_t km1 = k - 1;
+    uint64_t base = (uint64_t)blockIdx.x * CHUNK;
+    stage_chunk(fasta, base, n_bytes, lds);
+    __syncthreads();
+    uint32_t nb = piece_len(base, n_bytes);
+    L1 tot1;
+    L1 st1 = wg_excl_scan_l1(piece_l1(lds, nb), chunk_l1_state[blockIdx.x], sh1, &tot1);
+    uint32_t ls = l1_kind(st1);
+    L2 tot2;
+    L2 st2 = wg_excl_scan_l2(piece_l2(lds, nb, ls, km1), chunk_l2_state[blockIdx.x], sh2, &tot2, km1);
+
+    // exact parser state at this lane's first byte
+    uint64_t pend = st2.p_tail;
+    uint32_t run = l2_len(st2);
+    uint32_t rec = st2.rec;                        // headers seen so far; 0 = before the first record
+    const KT mask = (KT)((k >= sizeof(KT) * 4) ? ~(KT)0 : (((KT)1 << (2 * k)) - 1));
+    const uint32_t top = 2 * km1;
+    KT fwd = (KT)st2.bits, rev = 0;
+    for (uint32_t i = 0; i < run; i++) {           // rebuild the reverse-complement value of the carried bases
+        uint32_t b = (st2.bits >> (2 * (run - 1 - i))) & 3u;
+        rev = (rev >> 2) | ((KT)(3u - b) << top);
+    }
+    uint64_t seq_acc = 0, kmer_acc = 0, seq_tot = 0, kmer_tot = 0, name_end = 0;
+    const uint64_t pos0 = stream_off + base + (uint64_t)threadIdx.x * PIECE;
+    DirectSink sink;
+    sink.init(table32);
+
+    auto flush_rec = [&]() {
+        if (rec && rec <= recs_cap) {
+            if (seq_acc) atomicAdd((unsigned long long *)&recs[rec - 1].seq_len, (unsigned long long)seq_acc);
+            if (kmer_acc) atomicAdd((unsigned long long *)&recs[rec - 1].n_valid, (unsigned long long)kmer_acc);
+            if (name_end) atomicMax((unsigned long long *)&recs[rec - 1].name_end, (unsigned long long)name_end);
+        }
+        if (rec) { seq_tot += seq_acc; kmer_tot += kmer_acc; }   // text before the first header belongs to no record
+        seq_acc = 0; kmer_acc = 0; name_end = 0;
+    };
+
+    for_each_byte(lds, nb, [&](uint32_t i, uint32_t c) {
+        if (is_term(c)) { pend = 0; ls = LS_START; return; }
+        bool ws = is_ws(c);
+        if (ls == LS_START) {
+            if (ws) return;
+            if (c == '>') {                                   // indexer.py:66-82: new record
+                flush_rec();
+                rec++;
+                if (rec <= recs_cap) recs[rec - 1].name_off = pos0 + i + 1;
+                name_end = pos0 + i + 1;
+                run = 0;
+                ls = LS_HEADER;
+                return;
+            }
+            ls = LS_SEQ;
+        } else if (ls == LS_HEADER) {
+            if (!ws) name_end = pos0 + i + 1;
+            return;
+        } else if (ws) { pend++; return; }
+        // sequence character (indexer.py:75-78): counts towards seq_len whether valid or not
+        if (pend) { seq_acc += pend; run = 0; pend = 0; }     // the blanks were interior: each maps to None
+        seq_acc++;
+        uint32_t code = base_code(c);
+        if (code > 3u) { run = 0; return; }
+        fwd = (KT)(((fwd << 2) | (KT)code) & mask);           // indexer.py:149
+        rev = (KT)((rev >> 2) | ((KT)(3u - code) << top));    // indexer.py:150
+        if (run < k) run++;
+        if (run == k && rec) {                                // text before the first header is dropped (indexer.py:80-82)
+            sink.emit((uint64_t)(fwd < rev ? fwd : rev));     // indexer.py:341
+            kmer_acc++;
+        }
+    });
+    sink.flush();
+    flush_rec();
+
+    // totals: wave reduce, one atomic per wave
+    for (int d = 32; d; d >>= 1) {
+        seq_tot += __shfl_down((unsigned long long)seq_tot, d, 64);
+        kmer_tot += __shfl_down((unsigned long long)kmer_tot, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (seq_tot) atomicAdd((unsigned long long *)&carry->total_bp, (unsigned long long)seq_tot);
+        if (kmer_tot) atomicAdd((unsigned long long *)&carry->num_kmers, (unsigned long long)kmer_tot);
+    }
+}
+
+// ------------------------------------------------------------------ clamp + histogram ----------
+// SRC32: read u32 counters, write min(255, x) as u8 (16 per lane, one dwordx4 store) and count the
+// 256 values; !SRC32: histogram an existing u8 table (Header.update_stats, tools.py:246-263).
+// Zero and one -- by far the commonest values of a k-mer table -- are counted in registers; the rest
+// go through a per-wave LDS histogram so hot bins do not serialise on one LDS address per workgroup.
+template <bool SRC32>
+__global__ __launch_bounds__(WG) void k_hist(const void *__restrict__ src, uint8_t *__restrict__ dst8, uint64_t n,
+                                             unsigned long long *__restrict__ hist /*[256]*/) {
+    __shared__ uint32_t h[WG / 64][256];
+    for (int i = threadIdx.x; i < (WG / 64) * 256; i += WG) (&h[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t *myh = h[threadIdx.x >> 6];
+    uint64_t ones = 0;
+    const uint64_t n16 = n / 16;
+    for (uint64_t g = (uint64_t)blockIdx.x * WG + threadIdx.x; g < n16; g += (uint64_t)gridDim.x * WG) {
+        uint32_t v[16];
+        if (SRC32) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(src) + g * 4;
+            uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+            uint32_t t[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+            uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 16; j++) { v[j] = t[j] > 255u ? 255u : t[j]; o[j >> 2] |= v[j] << (8 * (j & 3)); }
+            reinterpret_cast<uint4 *>(dst8)[g] = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            uint4 a = reinterpret_cast<const uint4 *>(src)[g];
+            uint32_t t[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = (t[j >> 2] >> (8 * (j & 3))) & 0xffu;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (v[j] == 1u) ones++;
+            else if (v[j]) atomicAdd(&myh[v[j]], 1u);
+        }
+    }
+    // tail (n not a multiple of 16): first workgroup, one element per lane
+    if (blockIdx.x == 0) {
+        for (uint64_t i = n16 * 16 + threadIdx.x; i < n; i += WG) {
+            uint32_t x;
+            if (SRC32) { x = reinterpret_cast<const uint32_t *>(src)[i]; x = x > 255u ? 255u : x; dst8[i] = (uint8_t)x; }
+            else x = reinterpret_cast<const uint8_t *>(src)[i];
+            if (x == 1u) ones++;
+            else if (x) atomicAdd(&myh[x], 1u);
+        }
+    }
+    for (int d = 32; d; d >>= 1) ones += __shfl_down((unsigned long long)ones, d, 64);
+    if ((threadIdx.x & 63) == 0 && ones) atomicAdd(&hist[1], (unsigned long long)ones);
+    __syncthreads();
+    for (int b = threadIdx.x; b < 256; b += WG) {
+        unsigned long long s = 0;
+        for (int w = 0; w < WG / 64; w++) s += h[w][b];
+        if (s) atomicAdd(&hist[b], s);
+    }
+}
+
+// In-place clamp of the u32 counters (keeps long streams from wrapping 2^32 on one address).
+__global__ __launch_bounds__(WG) void k_clamp32(uint32_t *__restrict__ t, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * WG) {
+        uint32_t x = t[i];
+        if (x > 255u) t[i] = 255u;
+    }
+}
+
+// ------------------------------------------------------------------ launchers ------------------
+void launch_chunk_l1(const uint8_t *fasta, uint64_t n, L1 *chunk_l1, uint32_t n_chunks, hipStream_t s) {
+    hipLaunchKernelGGL(k_chunk_l1, dim3(n_chunks), dim3(WG), 0, s, fasta, n, chunk_l1);
+}
+void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_scan_l1, dim3(1), dim3(SCAN_T), 0, s, in, n_chunks, carry, out);
+}
+void launch_chunk_l2(const uint8_t *fasta, uint64_t n, const L1 *st1, L2 *chunk_l2, uint32_t n_chunks, uint32_t k, hipStream_t s) {
+    hipLaunchKernelGGL(k_chunk_l2, dim3(n_chunks), dim3(WG), 0, s, fasta, n, st1, chunk_l2, k - 1);
+}
+void launch_scan_l2(const L2 *in, uint32_t n_chunks, Carry *carry, L2 *out, uint32_t k, hipStream_t s) {
+    hipLaunchKernelGGL(k_scan_l2, dim3(1), dim3(SCAN_T), 0, s, in, n_chunks, carry, out, k - 1);
+}
+void launch_count(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const L1 *st1, const L2 *st2, uint32_t n_chunks,
+                  uint32_t k, uint32_t *table32, DevRec *recs, uint64_t recs_cap, Carry *carry, hipStream_t s) {
+    if (k <= 15)
+        hipLaunchKernelGGL(k_count<uint32_t>, dim3(n_chunks), dim3(WG), 0, s, fasta, n, stream_off, st1, st2, k, table32, recs, recs_cap, carry);
+    else
+        hipLaunchKernelGGL(k_count<uint64_t>, dim3(n_chunks), dim3(WG), 0, s, fasta, n, stream_off, st1, st2, k, table32, recs, recs_cap, carry);
+}
+static uint32_t stream_grid(uint64_t items_per_thread_units) {
+    uint64_t g = (items_per_thread_units + WG - 1) / WG;
+    if (g > 256u * 8u) g = 256u * 8u;
+    if (g == 0) g = 1;
+    return (uint32_t)g;
+}
+void launch_finalize(const uint32_t *table32, uint8_t *table8, uint64_t n, unsigned long long *hist, hipStream_t s) {
+    hipLaunchKernelGGL(k_hist<true>, dim3(stream_grid(n / 16 + 1)), dim3(WG), 0, s, (const void *)table32, table8, n, hist);
+}
+void launch_hist8(const uint8_t *table8, uint64_t n, unsigned long long *hist, hipStream_t s) {
+    hipLaunchKernelGGL(k_hist<false>, dim3(stream_grid(n / 16 + 1)), dim3(WG), 0, s, (const void *)table8, (uint8_t *)nullptr, n, hist);
+}
+void launch_clamp32(uint32_t *table32, uint64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_clamp32, dim3(stream_grid(n)), dim3(WG), 0, s, table32, n);
+}
+
+}  // namespace pk

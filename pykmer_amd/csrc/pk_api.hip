@@ -1,0 +1,434 @@
+// pk_api.hip -- host side of the C-ABI declared in include/pykmer_hip.h.
+// Owns device memory, streams and events; sequences the kernels of kmer_count.hip / gram_scan.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pykmer_hip.h"
+#include "pk_kernels.h"
+
+using namespace pk;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) return fail(PK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" int pk_version(void) { return PK_ABI_VERSION; }
+
+extern "C" int pk_last_error(char *buf, size_t n) {
+    if (!buf || n == 0) return PK_ERR_ARG;
+    snprintf(buf, n, "%s", g_err.c_str());
+    return PK_OK;
+}
+
+extern "C" int pk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int check_k(int k) {
+    // tools.py:165-167: k > 0 and odd.  The device path keeps the carried bases in 32 bits: k <= 17.
+    if (k <= 0 || (k % 2) == 0) return fail(PK_ERR_ARG, "kmer_len must be positive and odd (tools.py:165-167), got %d", k);
+    if (k > 17) return fail(PK_ERR_ARG, "kmer_len %d not supported by the device path (max 17: 4^17 = 16 GiB table)", k);
+    return PK_OK;
+}
+
+// ================================================================== indexer ====================
+struct pk_indexer {
+    int k = 0, device = 0;
+    uint64_t n = 0;                  // 4^k
+    hipStream_t stream = nullptr;
+    uint32_t *table32 = nullptr;     // counters while counting
+    uint8_t *table8 = nullptr;       // finished .kin image
+    Carry *carry = nullptr;
+    unsigned long long *hist = nullptr;
+    DevRec *recs = nullptr;
+    uint64_t recs_cap = 0;
+    L1 *c_l1 = nullptr, *c_l1s = nullptr;
+    L2 *c_l2 = nullptr, *c_l2s = nullptr;
+    uint32_t chunk_cap = 0;
+    uint8_t *staging = nullptr;      // device copy of host-fed bytes
+    uint64_t staging_cap = 0;
+    uint64_t bytes_fed = 0, since_clamp = 0, n_recs = 0;
+    bool finished = false;
+    hipEvent_t ev[8] = {};
+    double t_scan = 0, t_count = 0, t_final = 0, t_zero = 0;
+    int count_launches = 0;
+};
+
+static int ix_reset(pk_indexer *ix) {
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipEventRecord(ix->ev[6], ix->stream));
+    HIPCHK(hipMemsetAsync(ix->table32, 0, ix->n * sizeof(uint32_t), ix->stream));
+    HIPCHK(hipEventRecord(ix->ev[7], ix->stream));
+    Carry c;
+    memset(&c, 0, sizeof c);
+    c.l1 = 8u | 1u | (LS_START << 1);                    // l1_state(LS_START)
+    c.l2.flags = F_NONID | F_PRESET | F_BRK;             // l2_state(0, 0, 0, 0)
+    HIPCHK(hipMemcpyAsync(ix->carry, &c, sizeof c, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(hipMemsetAsync(ix->hist, 0, 256 * sizeof(unsigned long long), ix->stream));
+    if (ix->recs) HIPCHK(hipMemsetAsync(ix->recs, 0, ix->recs_cap * sizeof(DevRec), ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ix->ev[6], ix->ev[7]));
+    ix->t_zero = ms * 1e-3;
+    ix->bytes_fed = ix->since_clamp = ix->n_recs = 0;
+    ix->finished = false;
+    ix->t_scan = ix->t_count = ix->t_final = 0;
+    ix->count_launches = 0;
+    return PK_OK;
+}
+
+extern "C" void pk_indexer_destroy(pk_indexer *ix) {
+    if (!ix) return;
+    hipSetDevice(ix->device);
+    if (ix->stream) hipStreamSynchronize(ix->stream);
+    hipFree(ix->table32); hipFree(ix->table8); hipFree(ix->carry); hipFree(ix->hist); hipFree(ix->recs);
+    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->staging);
+    for (auto &e : ix->ev) if (e) hipEventDestroy(e);
+    if (ix->stream) hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+extern "C" int pk_indexer_create(pk_indexer **out, int k, int device) {
+    if (!out) return fail(PK_ERR_ARG, "null output pointer");
+    *out = nullptr;
+    int rc = check_k(k);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device));
+    pk_indexer *ix = new pk_indexer();
+    ix->k = k; ix->device = device; ix->n = 1ULL << (2 * k);
+    auto bail = [&](hipError_t e, const char *what) {
+        int r = fail(PK_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+        std::string keep = g_err;
+        pk_indexer_destroy(ix);
+        g_err = keep;
+        return r;
+    };
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    for (auto &ev : ix->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipMalloc(&ix->table32, ix->n * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(u32 table)");
+    if ((e = hipMalloc(&ix->table8, std::max<uint64_t>(ix->n, 16))) != hipSuccess) return bail(e, "hipMalloc(u8 table)");
+    if ((e = hipMalloc(&ix->carry, sizeof(Carry))) != hipSuccess) return bail(e, "hipMalloc(carry)");
+    if ((e = hipMalloc(&ix->hist, 256 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(hist)");
+    rc = ix_reset(ix);
+    if (rc) { std::string keep = g_err; pk_indexer_destroy(ix); g_err = keep; return rc; }
+    *out = ix;
+    return PK_OK;
+}
+
+extern "C" int pk_indexer_reset(pk_indexer *ix) {
+    if (!ix) return fail(PK_ERR_ARG, "null indexer");
+    return ix_reset(ix);
+}
+
+static int ensure_chunks(pk_indexer *ix, uint32_t n_chunks) {
+    if (n_chunks <= ix->chunk_cap) return PK_OK;
+    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s);
+    ix->c_l1 = ix->c_l1s = nullptr; ix->c_l2 = ix->c_l2s = nullptr; ix->chunk_cap = 0;
+    HIPCHK(hipMalloc(&ix->c_l1, n_chunks * sizeof(L1)));
+    HIPCHK(hipMalloc(&ix->c_l1s, n_chunks * sizeof(L1)));
+    HIPCHK(hipMalloc(&ix->c_l2, n_chunks * sizeof(L2)));
+    HIPCHK(hipMalloc(&ix->c_l2s, n_chunks * sizeof(L2)));
+    ix->chunk_cap = n_chunks;
+    return PK_OK;
+}
+
+static int ensure_recs(pk_indexer *ix, uint64_t need) {
+    if (need <= ix->recs_cap) return PK_OK;
+    uint64_t cap = std::max<uint64_t>(need, std::max<uint64_t>(1024, ix->recs_cap * 2));
+    DevRec *nr = nullptr;
+    HIPCHK(hipMalloc(&nr, cap * sizeof(DevRec)));
+    HIPCHK(hipMemsetAsync(nr, 0, cap * sizeof(DevRec), ix->stream));
+    if (ix->recs && ix->recs_cap)
+        HIPCHK(hipMemcpyAsync(nr, ix->recs, ix->recs_cap * sizeof(DevRec), hipMemcpyDeviceToDevice, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    hipFree(ix->recs);
+    ix->recs = nr; ix->recs_cap = cap;
+    return PK_OK;
+}
+
+extern "C" int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uint64_t n_bytes) {
+    if (!ix) return fail(PK_ERR_ARG, "null indexer");
+    if (ix->finished) return fail(PK_ERR_STATE, "indexer already finished; reset it first");
+    if (n_bytes == 0) return PK_OK;
+    if (!dev_fasta || ((uintptr_t)dev_fasta & 15u)) return fail(PK_ERR_ARG, "device FASTA pointer must be non-null and 16-byte aligned");
+    if (n_bytes > (1ULL << 40)) return fail(PK_ERR_ARG, "feed of %llu bytes too large; split it", (unsigned long long)n_bytes);
+    HIPCHK(hipSetDevice(ix->device));
+    // u32 counters: clamp before any single address could wrap (one k-mer per byte at most)
+    if (ix->since_clamp + n_bytes >= 0xFFFFFF00ULL) {
+        if (n_bytes >= 0xFFFFFF00ULL) return fail(PK_ERR_ARG, "single feed must stay below 4 GiB");
+        launch_clamp32(ix->table32, ix->n, ix->stream);
+        ix->since_clamp = 0;
+    }
+    const uint32_t n_chunks = (uint32_t)((n_bytes + CHUNK - 1) / CHUNK);
+    int rc = ensure_chunks(ix, n_chunks);
+    if (rc) return rc;
+    const uint8_t *f = (const uint8_t *)dev_fasta;
+    HIPCHK(hipEventRecord(ix->ev[0], ix->stream));
+    launch_chunk_l1(f, n_bytes, ix->c_l1, n_chunks, ix->stream);
+    launch_scan_l1(ix->c_l1, n_chunks, ix->carry, ix->c_l1s, ix->stream);
+    launch_chunk_l2(f, n_bytes, ix->c_l1s, ix->c_l2, n_chunks, (uint32_t)ix->k, ix->stream);
+    launch_scan_l2(ix->c_l2, n_chunks, ix->carry, ix->c_l2s, (uint32_t)ix->k, ix->stream);
+    HIPCHK(hipEventRecord(ix->ev[1], ix->stream));
+    uint64_t n_recs = 0;
+    HIPCHK(hipMemcpyAsync(&n_recs, &ix->carry->n_recs, sizeof n_recs, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    rc = ensure_recs(ix, n_recs);
+    if (rc) return rc;
+    ix->n_recs = n_recs;
+    HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
+    launch_count(f, n_bytes, ix->bytes_fed, ix->c_l1s, ix->c_l2s, n_chunks, (uint32_t)ix->k, ix->table32, ix->recs, ix->recs_cap,
+                 ix->carry, ix->stream);
+    HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    float a = 0, b = 0;
+    HIPCHK(hipEventElapsedTime(&a, ix->ev[0], ix->ev[1]));
+    HIPCHK(hipEventElapsedTime(&b, ix->ev[2], ix->ev[3]));
+    ix->t_scan += a * 1e-3; ix->t_count += b * 1e-3; ix->count_launches++;
+    ix->bytes_fed += n_bytes; ix->since_clamp += n_bytes;
+    return PK_OK;
+}
+
+extern "C" int pk_indexer_feed(pk_indexer *ix, const uint8_t *host_fasta, uint64_t n_bytes) {
+    if (!ix) return fail(PK_ERR_ARG, "null indexer");
+    if (n_bytes == 0) return PK_OK;
+    if (!host_fasta) return fail(PK_ERR_ARG, "null FASTA pointer");
+    HIPCHK(hipSetDevice(ix->device));
+    const uint64_t PIECE_MAX = 1ULL << 30;               // stage at most 1 GiB at a time
+    for (uint64_t off = 0; off < n_bytes; off += PIECE_MAX) {
+        uint64_t len = std::min(PIECE_MAX, n_bytes - off);
+        if (len + 64 > ix->staging_cap) {
+            hipFree(ix->staging); ix->staging = nullptr; ix->staging_cap = 0;
+            HIPCHK(hipMalloc(&ix->staging, len + 64));
+            ix->staging_cap = len + 64;
+        }
+        HIPCHK(hipMemcpyAsync(ix->staging, host_fasta + off, len, hipMemcpyHostToDevice, ix->stream));
+        int rc = pk_indexer_feed_device(ix, ix->staging, len);
+        if (rc) return rc;
+    }
+    return PK_OK;
+}
+
+extern "C" int pk_indexer_finish(pk_indexer *ix, uint64_t *num_kmers_out, uint64_t *total_bp_out, uint64_t hist256_out[256],
+                                 uint64_t *n_recs_out) {
+    if (!ix) return fail(PK_ERR_ARG, "null indexer");
+    HIPCHK(hipSetDevice(ix->device));
+    if (!ix->finished) {
+        HIPCHK(hipEventRecord(ix->ev[4], ix->stream));
+        launch_finalize(ix->table32, ix->table8, ix->n, ix->hist, ix->stream);
+        HIPCHK(hipEventRecord(ix->ev[5], ix->stream));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ix->ev[4], ix->ev[5]));
+        ix->t_final = ms * 1e-3;
+        ix->finished = true;
+    }
+    Carry c;
+    HIPCHK(hipMemcpy(&c, ix->carry, sizeof c, hipMemcpyDeviceToHost));
+    if (num_kmers_out) *num_kmers_out = c.num_kmers;
+    if (total_bp_out) *total_bp_out = c.total_bp;
+    if (n_recs_out) *n_recs_out = c.n_recs;
+    if (hist256_out) {
+        unsigned long long h[256];
+        HIPCHK(hipMemcpy(h, ix->hist, sizeof h, hipMemcpyDeviceToHost));
+        uint64_t nonzero = 0;
+        for (int v = 1; v < 256; v++) { hist256_out[v] = h[v]; nonzero += h[v]; }
+        hist256_out[0] = ix->n - nonzero;                // zeros are not tallied on the device
+    }
+    return PK_OK;
+}
+
+extern "C" int pk_indexer_records(pk_indexer *ix, pk_record *recs_out, uint64_t recs_cap) {
+    if (!ix) return fail(PK_ERR_ARG, "null indexer");
+    if (ix->n_recs > recs_cap) return fail(PK_ERR_RECS_CAP, "%llu records, capacity %llu", (unsigned long long)ix->n_recs, (unsigned long long)recs_cap);
+    if (ix->n_recs == 0) return PK_OK;
+    if (!recs_out) return fail(PK_ERR_ARG, "null records pointer");
+    HIPCHK(hipSetDevice(ix->device));
+    std::vector<DevRec> tmp(ix->n_recs);
+    HIPCHK(hipMemcpy(tmp.data(), ix->recs, ix->n_recs * sizeof(DevRec), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < ix->n_recs; i++) {
+        recs_out[i].name_off = tmp[i].name_off;
+        recs_out[i].name_len = tmp[i].name_end > tmp[i].name_off ? tmp[i].name_end - tmp[i].name_off : 0;
+        recs_out[i].seq_len = tmp[i].seq_len;
+        recs_out[i].n_valid_kmers = tmp[i].n_valid;
+    }
+    return PK_OK;
+}
+
+extern "C" int pk_indexer_table_to_host(pk_indexer *ix, uint8_t *table_out) {
+    if (!ix || !table_out) return fail(PK_ERR_ARG, "null argument");
+    if (!ix->finished) return fail(PK_ERR_STATE, "call pk_indexer_finish first");
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipMemcpy(table_out, ix->table8, ix->n, hipMemcpyDeviceToHost));
+    return PK_OK;
+}
+
+extern "C" int pk_indexer_table_device(pk_indexer *ix, const void **dev_table_out) {
+    if (!ix || !dev_table_out) return fail(PK_ERR_ARG, "null argument");
+    if (!ix->finished) return fail(PK_ERR_STATE, "call pk_indexer_finish first");
+    *dev_table_out = ix->table8;
+    return PK_OK;
+}
+
+extern "C" int pk_indexer_timings(pk_indexer *ix, double out[8]) {
+    if (!ix || !out) return fail(PK_ERR_ARG, "null argument");
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    out[0] = ix->t_scan; out[1] = ix->t_count; out[2] = ix->t_final; out[3] = ix->t_zero; out[4] = (double)ix->count_launches;
+    return PK_OK;
+}
+
+extern "C" int pk_count_fasta(const uint8_t *fasta, uint64_t n_bytes, int k, uint8_t *table_out, uint64_t *num_kmers_out,
+                              uint64_t *total_bp_out, uint64_t hist256_out[256], pk_record *recs_out, uint64_t recs_cap,
+                              uint64_t *n_recs_out, int device) {
+    int rc = check_k(k);
+    if (rc) return rc;
+    if (!table_out) return fail(PK_ERR_ARG, "null table pointer");
+    if (n_bytes && !fasta) return fail(PK_ERR_ARG, "null FASTA pointer");
+    pk_indexer *ix = nullptr;
+    rc = pk_indexer_create(&ix, k, device);
+    if (rc) return rc;
+    auto done = [&](int r) { std::string keep = g_err; pk_indexer_destroy(ix); g_err = keep; return r; };
+    if ((rc = pk_indexer_feed(ix, fasta, n_bytes))) return done(rc);
+    uint64_t n_recs = 0;
+    if ((rc = pk_indexer_finish(ix, num_kmers_out, total_bp_out, hist256_out, &n_recs))) return done(rc);
+    if (n_recs_out) *n_recs_out = n_recs;
+    if ((rc = pk_indexer_table_to_host(ix, table_out))) return done(rc);
+    if (n_recs > recs_cap) return done(fail(PK_ERR_RECS_CAP, "%llu records, capacity %llu", (unsigned long long)n_recs, (unsigned long long)recs_cap));
+    if ((rc = pk_indexer_records(ix, recs_out, recs_cap))) return done(rc);
+    return done(PK_OK);
+}
+
+// ================================================================== stats ======================
+extern "C" int pk_table_stats(const uint8_t *table, uint64_t n, uint64_t hist256_out[256], int device) {
+    if (!hist256_out || (n && !table)) return fail(PK_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(device));
+    unsigned long long *d_hist = nullptr;
+    uint8_t *d_t = nullptr;
+    HIPCHK(hipMalloc(&d_hist, 256 * sizeof(unsigned long long)));
+    hipError_t e = hipMalloc(&d_t, std::max<uint64_t>(n, 16));
+    if (e != hipSuccess) { hipFree(d_hist); return fail(PK_ERR_HIP, "hipMalloc(table) failed: %s", hipGetErrorString(e)); }
+    int rc = PK_OK;
+    unsigned long long h[256];
+    if (hipMemset(d_hist, 0, 256 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemcpy(d_t, table, n, hipMemcpyHostToDevice) != hipSuccess) rc = fail(PK_ERR_HIP, "upload failed");
+    if (!rc) {
+        launch_hist8(d_t, n, d_hist, 0);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, d_hist, sizeof h, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(PK_ERR_HIP, "histogram kernel failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    hipFree(d_t); hipFree(d_hist);
+    if (rc) return rc;
+    uint64_t nz = 0;
+    for (int v = 1; v < 256; v++) { hist256_out[v] = h[v]; nz += h[v]; }
+    hist256_out[0] = n - nz;
+    return PK_OK;
+}
+
+// ================================================================== merger =====================
+static int check_counts(int N, int min_count, int max_count) {
+    if (N < 1) return fail(PK_ERR_ARG, "need at least one table");
+    if (N > 128) return fail(PK_ERR_ARG, "at most 128 tables per call (got %d)", N);
+    if (min_count < 1 || max_count > 255) return fail(PK_ERR_ARG, "min_count must be >= 1 and max_count <= 255 (merger.py:90-91)");
+    return PK_OK;
+}
+
+extern "C" int pk_gram_expand(const uint64_t *pair, int N, uint64_t *matrix_out) {
+    if (!pair || !matrix_out || N < 1) return fail(PK_ERR_ARG, "bad argument");
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) {
+            uint64_t *m = matrix_out + ((uint64_t)i * N + j) * 3;
+            if (i == j) { m[0] = m[1] = m[2] = 0; continue; }              // merger.py:136: never assigned
+            m[0] = pair[(uint64_t)i * N + i];                                // merger.py:175-176
+            m[1] = pair[(uint64_t)j * N + j];
+            m[2] = i < j ? pair[(uint64_t)i * N + j] : pair[(uint64_t)j * N + i];
+        }
+    return PK_OK;
+}
+
+extern "C" int pk_gram_device_partial(const void *const *dev_tables, int N, uint64_t n_slice, int min_count, int max_count,
+                                      uint64_t *pair_out, void *dev_pair_out, int device, double *kernel_seconds_out) {
+    int rc = check_counts(N, min_count, max_count);
+    if (rc) return rc;
+    if (!dev_tables) return fail(PK_ERR_ARG, "null table list");
+    for (int i = 0; i < N; i++)
+        if (!dev_tables[i] || ((uintptr_t)dev_tables[i] & 15u)) return fail(PK_ERR_ARG, "table %d: device pointer must be 16-byte aligned", i);
+    HIPCHK(hipSetDevice(device));
+    const uint8_t **d_ptrs = nullptr;
+    unsigned long long *d_pair = (unsigned long long *)dev_pair_out;
+    bool own_pair = false;
+    HIPCHK(hipMalloc(&d_ptrs, N * sizeof(void *)));
+    if (!d_pair) {
+        hipError_t e = hipMalloc(&d_pair, (size_t)N * N * sizeof(unsigned long long));
+        if (e != hipSuccess) { hipFree(d_ptrs); return fail(PK_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
+        own_pair = true;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    rc = PK_OK;
+    if (hipMemcpy(d_ptrs, dev_tables, N * sizeof(void *), hipMemcpyHostToDevice) != hipSuccess) rc = fail(PK_ERR_HIP, "pointer upload failed");
+    if (!rc) {
+        hipEventRecord(e0, 0);
+        int lr = launch_gram(d_ptrs, N, n_slice, min_count, max_count, d_pair, 0);
+        hipEventRecord(e1, 0);
+        if (lr || hipDeviceSynchronize() != hipSuccess) rc = fail(PK_ERR_HIP, "gram kernel failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    if (!rc && kernel_seconds_out) { float ms = 0; hipEventElapsedTime(&ms, e0, e1); *kernel_seconds_out = ms * 1e-3; }
+    if (!rc && pair_out && hipMemcpy(pair_out, d_pair, (size_t)N * N * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(PK_ERR_HIP, "result download failed");
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(d_ptrs);
+    if (own_pair) hipFree(d_pair);
+    return rc;
+}
+
+extern "C" int pk_gram(const uint8_t *const *tables, int N, uint64_t n, int min_count, int max_count, uint64_t *matrix_out,
+                       const int *devices, int n_devices) {
+    int rc = check_counts(N, min_count, max_count);
+    if (rc) return rc;
+    if (!tables || !matrix_out) return fail(PK_ERR_ARG, "null argument");
+    int dev0 = 0;
+    if (!devices || n_devices <= 0) { devices = &dev0; n_devices = 1; }
+    std::vector<uint64_t> pair((size_t)N * N, 0), part((size_t)N * N);
+    // address range split into n_devices contiguous slices (multiples of 32 addresses)
+    uint64_t per = ((n + n_devices - 1) / n_devices + 31u) & ~31ULL;
+    for (int d = 0; d < n_devices; d++) {
+        uint64_t lo = std::min<uint64_t>(n, per * d), hi = std::min<uint64_t>(n, lo + per);
+        if (hi <= lo) continue;
+        HIPCHK(hipSetDevice(devices[d]));
+        std::vector<void *> dptr(N, nullptr);
+        rc = PK_OK;
+        for (int i = 0; i < N && !rc; i++) {
+            if (hipMalloc(&dptr[i], hi - lo + 32) != hipSuccess) { rc = fail(PK_ERR_HIP, "hipMalloc(table slice) failed"); break; }
+            if (hipMemcpy(dptr[i], tables[i] + lo, hi - lo, hipMemcpyHostToDevice) != hipSuccess) rc = fail(PK_ERR_HIP, "table upload failed");
+        }
+        if (!rc) rc = pk_gram_device_partial((const void *const *)dptr.data(), N, hi - lo, min_count, max_count, part.data(), nullptr, devices[d], nullptr);
+        for (auto p : dptr) hipFree(p);
+        if (rc) return rc;
+        for (size_t i = 0; i < pair.size(); i++) pair[i] += part[i];
+    }
+    return pk_gram_expand(pair.data(), N, matrix_out);
+}

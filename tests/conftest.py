@@ -1,0 +1,46 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_present() -> bool:
+    try:
+        from pykmer_amd import _lib
+        return _lib.device_count() > 0
+    except ImportError:
+        # a GPU box without the built library must FAIL, not skip: decide from the device nodes
+        return os.path.exists("/dev/kfd") and any(n.startswith("renderD") for n in os.listdir("/dev/dri")) \
+            if os.path.isdir("/dev/dri") else False
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """The loaded C-ABI library on a box with a GPU; skips only when there is no GPU at all."""
+    if not _gpu_present():
+        pytest.skip("no GPU visible")
+    from pykmer_amd import _lib
+    _lib.load()          # raises ImportError if the extension was not built: loud failure
+    return _lib
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="session")
+def small_tables():
+    import numpy as np
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "tables_small.npz")))

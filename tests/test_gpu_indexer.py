@@ -1,0 +1,172 @@
+"""GPU parity tests for the indexer path: HIP kernels (through the C-ABI) vs the oracle and vs the
+golden vectors the reference itself produced (tests/golden/, oracle/gen_golden.py).  Bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import inputs
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_against_oracle(gpu, data, k):
+    got = gpu.count_fasta(data, k)
+    want = oracle.count_fasta(data, k)
+    assert got["num_kmers"] == want["num_kmers"]
+    assert got["total_bp"] == want["total_bp"]
+    assert len(got["records"]) == len(want["records"])
+    for f in ("name_off", "name_len", "seq_len", "n_valid_kmers"):
+        assert np.array_equal(got["records"][f], want["records"][f]), f
+    assert np.array_equal(got["table"], want["table"])
+    hist, vals = oracle.table_stats(want["table"])
+    assert np.array_equal(got["hist256"][1:], hist)
+    assert int(got["hist256"].sum()) == 4 ** k
+    return got
+
+
+def _expect_fields(got, data, case):
+    e = case["expect"]
+    assert got["num_kmers"] == e["num_kmers"]
+    assert [list(c) for c in oracle.chromosomes(data, got["records"])] == e["chromosomes"]
+    h = got["hist256"]
+    assert h[1:].tolist() == e["hist"]
+    v = np.arange(256, dtype=np.uint64)
+    assert int((h * v).sum()) == e["vals_sum"]
+    assert int(h[1:].sum()) == e["vals_count"]
+    nz = np.nonzero(h)[0]
+    assert int(nz.min()) == e["vals_min"] and int(nz.max()) == e["vals_max"]
+    assert hashlib.sha256(got["table"].tobytes()).hexdigest() == e["output_file_cheksum"]
+
+
+@pytest.mark.parametrize("k", [1, 3, 5, 7, 9, 11, 13])
+def test_edge_fasta_vs_oracle(gpu, k):
+    _check_against_oracle(gpu, inputs.edge_fasta(), k)
+
+
+@pytest.mark.parametrize("name", ["G1_kat_k3", "G1_kat_k5", "G1_kat_k7", "G2_c1_k7", "G3_edge_k3", "G3_edge_k7",
+                                  "G3_edge_k9", "G5_c2_2M_k7"])
+def test_golden_small(gpu, manifest, small_tables, name):
+    case = manifest["indexer"][name]
+    data = inputs.make_input(case["input"])
+    assert inputs.sha256(data) == case["input_sha256"], "seeded input drifted"
+    got = gpu.count_fasta(data, case["k"])
+    assert np.array_equal(got["table"], small_tables[name])
+    _expect_fields(got, data, case)
+
+
+def test_kat_analytic(gpu):
+    """every k-mer once, k odd -> each canonical address holds exactly 2."""
+    k = 7
+    got = gpu.count_fasta(inputs.kat_fasta(k), k)
+    assert got["num_kmers"] == 4 ** k and got["hist256"][2] == 4 ** k // 2 and got["hist256"][0] == 4 ** k // 2
+    assert len(got["records"]) == 4 ** k and (got["records"]["n_valid_kmers"] == 1).all()
+
+
+@pytest.mark.parametrize("name", ["G3_edge_k15", "G5_c2_20M_k15", "G5_c1_4M_k13"])
+def test_golden_k13_k15(gpu, manifest, name):
+    case = manifest["indexer"][name]
+    data = inputs.make_input(case["input"])
+    assert inputs.sha256(data) == case["input_sha256"]
+    _expect_fields(gpu.count_fasta(data, case["k"]), data, case)
+
+
+def test_golden_k17(gpu, manifest):
+    """config 4 scaled: 4^17 = 16 GiB table resident in HBM (64 GiB of u32 counters while counting)."""
+    case = manifest["indexer"]["G5_c2_8M_k17"]
+    data = inputs.make_input(case["input"])
+    assert inputs.sha256(data) == case["input_sha256"]
+    _expect_fields(gpu.count_fasta(data, 17), data, case)
+
+
+def test_full_config2_k15(gpu, manifest):
+    """config 2: the ~800 Mbp synthetic genome at k=15, bit-exact against the reference's own run when
+    that golden exists (G6, ~1 h of reference time), and through size-independent properties always."""
+    data = inputs.make_input({"gen": "c2"})
+    got = gpu.count_fasta(data, 15)
+    h = got["hist256"]
+    v = np.arange(256, dtype=np.uint64)
+    assert int(h.sum()) == 4 ** 15
+    assert got["num_kmers"] == int(got["records"]["n_valid_kmers"].sum())
+    assert got["total_bp"] == int(got["records"]["seq_len"].sum()) == 800_000_000
+    assert int((h * v).sum()) <= got["num_kmers"]                       # saturation only ever loses counts
+    assert int((h[:255] * v[:255]).sum()) + 255 * int(h[255]) == int((h * v).sum())
+    tab = got["table"]
+    assert int(np.count_nonzero(tab[: 1 << 24])) == int(np.count_nonzero(tab[: 1 << 24] > 0))
+    assert int(tab[0]) == 255                                           # poly-A / poly-T runs saturate address 0
+    # a second, independent path to the same table: stream the same bytes in uneven pieces
+    with gpu.Indexer(15) as ix:
+        cuts = [0, 1, 17, 4097, 1 << 20, (1 << 28) + 5, len(data)]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ix.feed(data[a:b])
+        fin = ix.finish()
+        assert fin["num_kmers"] == got["num_kmers"] and np.array_equal(fin["hist256"], h)
+        assert np.array_equal(ix.table_to_host(), tab)
+    case = manifest["indexer"].get("G6_c2_800M_k15")
+    if case is not None:
+        assert inputs.sha256(data) == case["input_sha256"]
+        _expect_fields(got, data, case)
+
+
+def test_streaming_feed_equals_one_shot(gpu):
+    """Chunks may split lines, headers, records and k-mers anywhere (pk_indexer_feed)."""
+    data = inputs.edge_fasta()
+    for k in (7, 15):
+        want = oracle.count_fasta(data, k)
+        rng = np.random.default_rng(5)
+        for trial in range(3):
+            with gpu.Indexer(k) as ix:
+                if trial == 0:
+                    cuts = list(range(0, 600)) + [len(data)]            # one byte at a time through the preamble
+                else:
+                    cuts = sorted(set([0, len(data)] + rng.integers(0, len(data), size=40).tolist()))
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    ix.feed(data[a:b])
+                fin = ix.finish()
+                recs = ix.records(fin["n_records"])
+                assert fin["num_kmers"] == want["num_kmers"] and fin["total_bp"] == want["total_bp"]
+                for f in ("name_off", "name_len", "seq_len", "n_valid_kmers"):
+                    assert np.array_equal(recs[f], want["records"][f]), (k, trial, f)
+                assert np.array_equal(ix.table_to_host(), want["table"])
+
+
+def test_random_structure_fuzz(gpu):
+    """Random byte soup over the FASTA-relevant alphabet: every parser state transition, every seam."""
+    rng = np.random.default_rng(11)
+    alphabet = np.frombuffer(b"ACGTacgtNn>> \t\r\n\n\n\x0b\x0cXR", dtype=np.uint8)
+    for trial in range(6):
+        n = int(rng.integers(1, 70000))
+        w = rng.random(alphabet.size) ** 3
+        data = alphabet[rng.choice(alphabet.size, size=n, p=w / w.sum())].tobytes()
+        for k in (3, 9):
+            _check_against_oracle(gpu, data, k)
+
+
+def test_unwrapped_long_lines_and_empty(gpu):
+    rng = np.random.default_rng(3)
+    seq = "".join("ACGT"[i] for i in rng.integers(0, 4, size=300_000))
+    data = (">one_line_record\n" + seq + "\n>second\n" + seq[:100_000]).encode()      # 300 kbp on one line
+    _check_against_oracle(gpu, data, 11)
+    for blob in (b"", b"\n\n", b">only_header", b"ACGTACGTACGT\n", b">x\n" + b"A" * 20):
+        got = gpu.count_fasta(blob, 5)
+        want = oracle.count_fasta(blob, 5)
+        assert got["num_kmers"] == want["num_kmers"] and np.array_equal(got["table"], want["table"])
+        assert len(got["records"]) == len(want["records"])
+
+
+def test_table_stats(gpu):
+    rng = np.random.default_rng(1)
+    for n in (4, 64, 1000, 1 << 20):
+        t = rng.integers(0, 256, size=n, dtype=np.uint8)
+        t[rng.random(n) < 0.6] = 0
+        h = gpu.table_stats(t)
+        assert np.array_equal(h, np.bincount(t, minlength=256).astype(np.uint64))
+
+
+def test_rejects_bad_k(gpu):
+    for k in (0, -3, 4, 16):                                  # tools.py:165-167
+        with pytest.raises(ValueError):
+            gpu.count_fasta(b">a\nACGT\n", k)
+    with pytest.raises(ValueError):
+        gpu.count_fasta(b">a\nACGT\n", 19)                    # beyond the device path (256 GiB table)
