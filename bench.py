@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: bp/s of canonical k-mer counting at k=15 on the ~800 Mbp synthetic
+genome (BASELINE.json configs[1]), one genome per GPU (weak scaling), plus the
+N=13 k=15 merge scan as a secondary figure.
+
+A step = one whole indexing job on HBM-resident input: zero the 4^15 table, structure scans, the
+fused extract+count kernel, clamp+histogram.  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--bp 800000000] [--no-merge] [--no-cpu]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--bp", type=int, default=800_000_000, help="genome size (default: config 2)")
+    ap.add_argument("--k", type=int, default=15)
+    ap.add_argument("--merge-n", type=int, default=13)
+    ap.add_argument("--merge-bp", type=int, default=40_000_000, help="genome size behind each merge table")
+    ap.add_argument("--no-merge", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-bp", type=int, default=160_000_000, help="sample size for the CPU baseline")
+    args = ap.parse_args()
+
+    import torch
+    import synth
+    from pykmer_amd import _lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # ---- input: one synthetic genome per rank, resident in HBM before the clock starts
+    k = args.k
+    fasta, total_bp = synth.c2(args.bp, seed=2 + rank)
+    n_bytes = int(fasta.size)
+    d_fasta = torch.empty(n_bytes + 64, dtype=torch.uint8, device=dev)
+    d_fasta[:n_bytes].copy_(torch.from_numpy(fasta))
+    torch.cuda.synchronize()
+
+    ix = _lib.Indexer(k, device=local)
+
+    def step():
+        ix.reset()
+        ix.feed_device(d_fasta.data_ptr(), n_bytes)
+        return ix.finish()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    count_s = scan_s = final_s = zero_s = 0.0
+    fin = None
+    for _ in range(args.steps):
+        fin = step()
+        t = ix.timings()
+        count_s += t["count_s"]; scan_s += t["scan_s"]; final_s += t["finalize_s"]; zero_s += t["zero_s"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        bp_all = torch.tensor([total_bp], dtype=torch.int64, device=dev)
+        dist.all_reduce(bp_all)
+        bp_job = int(bp_all.item())
+    else:
+        bp_job = total_bp
+    assert fin["total_bp"] == total_bp, (fin["total_bp"], total_bp)
+    value = bp_job * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (k_count): algorithmic bytes = FASTA read once + table written once
+    alg_bytes = n_bytes + 4 ** k                                   # F + 4^k  (2.36 B/bp on C2 at k=15)
+    count_avg = count_s / args.steps
+    achieved = alg_bytes / count_avg / 1e9
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tp):
+        with open(tp) as fh:
+            traffic = json.load(fh).get("k_count", {}).get("bytes_per_launch")
+    out = {
+        "metric": "bp/s k-mer counted (k=15, 1 GPU)" if k == 15 else f"bp/s k-mer counted (k={k})",
+        "value": value, "unit": "bp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"k={k} canonical k-mer count of one {total_bp / 1e6:.0f} Mbp synthetic genome per GPU "
+                               f"(SURVEY 8d C2, seed 2+rank), 4^{k} table resident in HBM",
+                   "fasta_bytes": n_bytes, "num_kmers": fin["num_kmers"], "parallelism": f"{world} independent genome(s)"},
+        "roofline": {"bound": "hbm", "kernel": "k_count", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": count_avg * 1e3},
+        "stage_ms": {"zero_table": zero_s / args.steps * 1e3, "structure_scans": scan_s / args.steps * 1e3,
+                     "count_kernel": count_avg * 1e3, "clamp_histogram": final_s / args.steps * 1e3},
+    }
+
+    # ---- secondary: N x N merge scan at k=15 over N tables resident in HBM, address range sharded over ranks
+    if not args.no_merge:
+        N, n = args.merge_n, 4 ** k
+        lo = (n // world) * rank
+        hi = n if rank == world - 1 else (n // world) * (rank + 1)
+        slices = []
+        for i in range(N):
+            fa, _ = synth.family(i, args.merge_bp)
+            ix.reset()
+            ix.feed(fa)
+            ix.finish()
+            sl = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
+            ix.table_slice_to_device(sl.data_ptr(), lo, hi - lo)   # this rank's address slice stays in HBM
+            slices.append(sl)
+        d_pair = torch.zeros(N * N, dtype=torch.int64, device=dev)
+        ptrs = [s.data_ptr() for s in slices]
+        best, kern = None, None
+        for rep in range(4):
+            barrier()
+            t0 = time.perf_counter()
+            pair, ksec = _lib.gram_device_partial(ptrs, hi - lo, 1, 255, device=local, dev_pair_out=d_pair.data_ptr())
+            if dist is not None:
+                dist.all_reduce(d_pair)                            # RCCL sum of the N x N partials over xGMI
+            barrier()
+            dt = time.perf_counter() - t0
+            if rep and (best is None or dt < best):
+                best, kern = dt, ksec
+        out["merge"] = {"n_tables": N, "k": k, "seconds": best, "kernel_seconds_rank0": kern,
+                        "algorithmic_bytes": N * n, "kernel_GBps_aggregate": N * n / kern / 1e9 if world == 1 else None,
+                        "sharding": f"address range / {world} + all_reduce(N*N u64)" if world > 1 else "single GPU"}
+
+    # ---- CPU baseline: the oracle's C restatement, one core, bounded sample of the same workload
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import oracle
+        fa, bp = synth.c2(args.cpu_bp, seed=2)
+        tab = np.zeros(4 ** k, dtype=np.uint8)
+        t0 = time.perf_counter()
+        r = oracle.count_fasta(fa, k, table=tab)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": bp / dt, "unit": "bp/s", "cores": 1, "kind": "port",
+                               "sample": f"oracle/kmer_oracle.c on a {bp / 1e6:.0f} Mbp C2-profile genome at k={k} ({dt:.1f} s)",
+                               "host_cores_available": os.cpu_count()}
+        t0 = time.perf_counter()
+        _lib.count_fasta(fasta, k, device=local)
+        out["e2e_host_buffers_bp_per_s"] = total_bp / (time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,6 +73,9 @@ int pk_indexer_table_to_host(pk_indexer *ix, uint8_t *table_out);
 /* Device pointer of the finished u8 table (valid until reset/destroy) -- lets a merge run on tables
  * that never left HBM. */
 int pk_indexer_table_device(pk_indexer *ix, const void **dev_table_out);
+/* Copy table bytes [offset, offset+n_bytes) into another device buffer on the same device (keeps an
+ * address-range slice for a sharded merge while the indexer goes on to the next sample). */
+int pk_indexer_table_slice_to_device(pk_indexer *ix, void *dev_dst, uint64_t offset, uint64_t n_bytes);
 /* Seconds spent in the last feed_device..finish sequence per stage, measured with HIP events on the
  * indexer's stream: [0] structure scans, [1] k-mer extract+count kernel, [2] clamp+histogram,
  * [3] table zeroing, [4] count-kernel launches (as a double). */

@@ -29,6 +29,7 @@ _SIGNATURES = {
     "pk_indexer_records": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
     "pk_indexer_table_to_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "pk_indexer_table_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "pk_indexer_table_slice_to_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]),
     "pk_indexer_timings": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "pk_indexer_destroy": (None, [ctypes.c_void_p]),
     "pk_table_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int]),
@@ -142,6 +143,9 @@ class Indexer:
         p = ctypes.c_void_p()
         _check(load().pk_indexer_table_device(self._h, ctypes.byref(p)))
         return p.value
+
+    def table_slice_to_device(self, dev_dst: int, offset: int, n_bytes: int):
+        _check(load().pk_indexer_table_slice_to_device(self._h, ctypes.c_void_p(dev_dst), offset, n_bytes))
 
     def timings(self) -> dict:
         t = np.zeros(8, dtype=np.float64)

@@ -294,6 +294,15 @@ extern "C" int pk_indexer_table_device(pk_indexer *ix, const void **dev_table_ou
     return PK_OK;
 }
 
+extern "C" int pk_indexer_table_slice_to_device(pk_indexer *ix, void *dev_dst, uint64_t offset, uint64_t n_bytes) {
+    if (!ix || !dev_dst) return fail(PK_ERR_ARG, "null argument");
+    if (!ix->finished) return fail(PK_ERR_STATE, "call pk_indexer_finish first");
+    if (offset > ix->n || n_bytes > ix->n - offset) return fail(PK_ERR_ARG, "slice outside the table");
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipMemcpy(dev_dst, ix->table8 + offset, n_bytes, hipMemcpyDeviceToDevice));
+    return PK_OK;
+}
+
 extern "C" int pk_indexer_timings(pk_indexer *ix, double out[8]) {
     if (!ix || !out) return fail(PK_ERR_ARG, "null argument");
     for (int i = 0; i < 8; i++) out[i] = 0;
