@@ -76,12 +76,13 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    count_s = scan_s = final_s = zero_s = 0.0
+    count_s = scan_s = final_s = zero_s = part_s = bucket_s = 0.0
     fin = None
     for _ in range(args.steps):
         fin = step()
         t = ix.timings()
         count_s += t["count_s"]; scan_s += t["scan_s"]; final_s += t["finalize_s"]; zero_s += t["zero_s"]
+        part_s += t["partition_s"]; bucket_s += t["bucket_s"]
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -117,7 +118,9 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": count_avg * 1e3},
         "stage_ms": {"zero_table": zero_s / args.steps * 1e3, "structure_scans": scan_s / args.steps * 1e3,
-                     "count_kernel": count_avg * 1e3, "clamp_histogram": final_s / args.steps * 1e3},
+                     "walk_kernel": count_avg * 1e3, "partition_passes": part_s / args.steps * 1e3,
+                     "bucket_count": bucket_s / args.steps * 1e3, "histogram": final_s / args.steps * 1e3,
+                     "mode": "direct" if t["direct"] else "partitioned"},
     }
 
     # ---- secondary: N x N merge scan at k=15 over N tables resident in HBM, address range sharded over ranks

@@ -76,9 +76,10 @@ int pk_indexer_table_device(pk_indexer *ix, const void **dev_table_out);
 /* Copy table bytes [offset, offset+n_bytes) into another device buffer on the same device (keeps an
  * address-range slice for a sharded merge while the indexer goes on to the next sample). */
 int pk_indexer_table_slice_to_device(pk_indexer *ix, void *dev_dst, uint64_t offset, uint64_t n_bytes);
-/* Seconds spent in the last feed_device..finish sequence per stage, measured with HIP events on the
- * indexer's stream: [0] structure scans, [1] k-mer extract+count kernel, [2] clamp+histogram,
- * [3] table zeroing, [4] count-kernel launches (as a double). */
+/* Seconds spent since the last reset per stage, measured with HIP events on the indexer's stream:
+ * [0] structure scans, [1] k-mer walk kernel (extract + route; in direct mode extract + atomic count),
+ * [2] histogram (direct mode: clamp+histogram), [3] table zeroing, [4] feeds (as a double),
+ * [5] partition passes, [6] bucket count + side list, [7] 1.0 if PK_COUNT_MODE=direct. */
 int pk_indexer_timings(pk_indexer *ix, double out[8]);
 void pk_indexer_destroy(pk_indexer *ix);
 

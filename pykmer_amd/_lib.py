@@ -51,6 +51,28 @@ class PkError(RuntimeError):
         self.code = code
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64 with the
+    same SONAMEs as /opt/rocm's; whichever is loaded first serves both, and torch fails ("no ROCm-capable
+    device") if the system copy got in first.  So when torch is installed, pull ITS copies in before our
+    library resolves the SONAMEs (no `import torch` needed); without torch the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 def load():
     """Loads the library (building nothing: run pykmer_amd.build or __graft_entry__.build first)."""
     global _lib
@@ -58,6 +80,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -m pykmer_amd.build` "
                               "(there is no CPU fallback)")
+        _share_torch_hip_runtime()
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
@@ -150,7 +173,8 @@ class Indexer:
     def timings(self) -> dict:
         t = np.zeros(8, dtype=np.float64)
         _check(load().pk_indexer_timings(self._h, t.ctypes.data))
-        return {"scan_s": t[0], "count_s": t[1], "finalize_s": t[2], "zero_s": t[3], "count_launches": int(t[4])}
+        return {"scan_s": t[0], "count_s": t[1], "finalize_s": t[2], "zero_s": t[3], "count_launches": int(t[4]),
+                "partition_s": t[5], "bucket_s": t[6], "direct": bool(t[7])}
 
 
 def count_fasta(data, k: int, device: int = 0, table_out: np.ndarray = None):

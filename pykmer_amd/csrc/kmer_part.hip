@@ -1,0 +1,684 @@
+// kmer_part.hip -- table update, version 2 ("partitioned"): no HBM atomics on the count table.
+//
+// Version 1 (kmer_count.hip, k_count) issues one global atomic per k-mer into a 4^k-entry table; on
+// MI355X scattered device-scope atomics execute at the memory side and top out near 4.6 G/s
+// (measured, profiles/round01_v1_direct_*), i.e. ~4.7 Gbp/s however good the parser is.  Here the
+// canonical k-mers are instead routed to the workgroup that owns their slice of the address space:
+//
+//   K0 k_walk_flat   FASTA -> canonical k-mers (same parser as v1), ballot-compacted per wave into
+//                    fixed per-(chunk,wave) regions of a flat record array; per-workgroup histogram
+//                    of the level-1 digit (top b1 address bits)
+//   K1 k_rows1_scan  column scan of those histograms -> exact output offset of every (workgroup, digit)
+//   K2 k_scatter     LDS counting sort of each 16K-record tile by digit, coalesced run writes
+//   K3 k_count2      per-workgroup histogram of the level-2 digit (next b2 bits) inside each level-1 bucket
+//   K4 k_rows2_scan  per-bucket column scan -> offsets + start of every final bucket
+//   K5 k_scatter     second pass, 16-bit records (address inside the final bucket)
+//   K6 k_bucket_count one workgroup per final bucket of 2^16 addresses: the slice of the u8 table
+//                    lives in LDS as 16-bit counters, ds_add per record, clamp, one coalesced
+//                    read-modify-write of the slice in HBM
+//
+// Every pass is a stream: FASTA 0.8 GB + records 3.1+3.1+3.1+3.1+1.5+1.5 GB + table 2x1 GiB at
+// k=15 / 800 Mbp.  Offsets come from histograms + scans, so no pass needs a global atomic and the
+// record order (hence the result) is deterministic.  Saturation is exact: min(255, .) is applied
+// only when a bucket's counters leave LDS (indexer.py:239,262), and K6 folds the slice already in
+// HBM back in, so several feeds accumulate exactly like the reference's flushes.
+#include "fasta_fsm.h"
+#include "pk_kernels.h"
+
+namespace pk {
+
+constexpr int SUB = 4096;            // record slots per (chunk, wave) region of the flat array = PIECE * 64 lanes
+constexpr int SC_T = 1024;           // threads of the scatter / bucket-count workgroups
+constexpr int SC_PER = 16;           // records per thread per tile
+constexpr int TILE = SC_T * SC_PER;  // 16384 records per tile = one FASTA chunk's worth
+
+// ------------------------------------------------------------------ hot keys ---------------------
+// Tandem repeats (poly-A/T, (AT)n, (AAG)n ...) put tens of millions of identical canonical k-mers on a
+// handful of addresses; routed like everything else they would all land in ONE final bucket, i.e. on
+// one CU.  Each lane therefore keeps the last four distinct k-mers it produced with run counts; only
+// entries seen once go into the record stream, entries seen >= 2 times are privatised in a per-
+// workgroup LDS hash table (addr -> count) that is appended to a global side list when the workgroup
+// finishes (or the table half fills).  k_apply_side folds the side list into the finished u8 table
+// with saturating CAS adds -- a few thousand entries instead of 10^7..10^8 records.
+constexpr uint32_t HOT_SLOTS = 1024;     // per-workgroup LDS hash slots
+constexpr uint32_t HOT_PROBES = 16;
+constexpr uint32_t SIDE_CNT_BITS = 28;   // side entry = (addr << 28) | count
+
+struct HotTable {
+    unsigned long long key[HOT_SLOTS];   // addr + 1, 0 = empty
+    uint32_t val[HOT_SLOTS];
+    uint32_t used, n_flush;
+};
+
+__device__ __forceinline__ void side_append_one(unsigned long long *side, unsigned long long *side_n, uint64_t side_cap,
+                                                uint64_t addr, uint32_t cnt) {
+    unsigned long long i = atomicAdd(side_n, 1ull);
+    if (i < side_cap) side[i] = ((unsigned long long)addr << SIDE_CNT_BITS) | cnt;
+}
+
+__device__ __forceinline__ void hot_insert(HotTable &H, uint64_t addr, uint32_t cnt, unsigned long long *side,
+                                           unsigned long long *side_n, uint64_t side_cap) {
+    const unsigned long long key = addr + 1ull;
+    uint32_t h = (uint32_t)((addr * 0x9E3779B97F4A7C15ull) >> 40) & (HOT_SLOTS - 1u);
+    for (uint32_t t = 0; t < HOT_PROBES; t++) {
+        unsigned long long old = atomicCAS(&H.key[h], 0ull, key);
+        if (old == 0ull || old == key) {
+            if (old == 0ull) atomicAdd(&H.used, 1u);
+            atomicAdd(&H.val[h], cnt);
+            return;
+        }
+        h = (h + 1u) & (HOT_SLOTS - 1u);
+    }
+    side_append_one(side, side_n, side_cap, addr, cnt);          // table crowded: straight to the side list
+}
+
+// all threads of the workgroup; appends every occupied slot to the side list and clears the table
+__device__ __forceinline__ void hot_flush(HotTable &H, unsigned long long *side, unsigned long long *side_n, uint64_t side_cap) {
+    __syncthreads();
+    if (threadIdx.x == 0) H.n_flush = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += blockDim.x) mine += H.key[i] != 0ull;
+    uint32_t at = mine ? atomicAdd(&H.n_flush, mine) : 0u;
+    __syncthreads();
+    __shared__ unsigned long long base64;
+    if (threadIdx.x == 0) base64 = H.n_flush ? atomicAdd(side_n, (unsigned long long)H.n_flush) : 0ull;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += blockDim.x) {
+        if (H.key[i] != 0ull) {
+            unsigned long long dst = base64 + at++;
+            if (dst < side_cap) side[dst] = ((H.key[i] - 1ull) << SIDE_CNT_BITS) | H.val[i];
+            H.key[i] = 0ull; H.val[i] = 0u;
+        }
+    }
+    if (threadIdx.x == 0) H.used = 0;
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ K0: walk -> flat records ----
+template <typename KT, typename REC0>
+__global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
+                                                  const L1 *__restrict__ chunk_l1_state, const L2 *__restrict__ chunk_l2_state,
+                                                  PartPlan pl, REC0 *__restrict__ flat, uint32_t *__restrict__ cnt,
+                                                  uint32_t *__restrict__ hist1_rows, DevRec *__restrict__ recs, uint64_t recs_cap,
+                                                  Carry *carry, unsigned long long *__restrict__ side,
+                                                  unsigned long long *__restrict__ side_n, uint64_t side_cap) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[WG * LDS_STRIDE];
+    __shared__ L1 sh1[WG / 64];
+    __shared__ L2 sh2[WG / 64];
+    __shared__ uint32_t hist1[512];
+    __shared__ HotTable hot;
+    for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += WG) { hot.key[i] = 0ull; hot.val[i] = 0u; }
+    if (threadIdx.x == 0) hot.used = 0;
+    const uint32_t k = pl.k, km1 = k - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t d = threadIdx.x; d < pl.B1; d += WG) hist1[d] = 0;
+    const KT mask = (KT)((k >= sizeof(KT) * 4) ? ~(KT)0 : (((KT)1 << (2 * k)) - 1));
+    const uint32_t top = 2 * km1;
+    const uint32_t shift1 = pl.addr_bits - pl.b1;
+    uint64_t seq_tot = 0, kmer_tot = 0;
+    const uint32_t c_lo = blockIdx.x * pl.G, c_hi = min(c_lo + pl.G, pl.n_chunks);
+    __syncthreads();
+    for (uint32_t c = c_lo; c < c_hi; c++) {
+        const uint64_t base = (uint64_t)c * CHUNK;
+        stage_chunk(fasta, base, n_bytes, lds);
+        __syncthreads();
+        const uint32_t nb = piece_len(base, n_bytes);
+        L1 tot1;
+        L1 st1 = wg_excl_scan_l1(piece_l1(lds, nb), chunk_l1_state[c], sh1, &tot1);
+        uint32_t ls = l1_kind(st1);
+        L2 tot2;
+        L2 st2 = wg_excl_scan_l2(piece_l2(lds, nb, ls, km1), chunk_l2_state[c], sh2, &tot2, km1);
+
+        uint64_t pend = st2.p_tail;
+        uint32_t run = l2_len(st2), rec = st2.rec;
+        KT fwd = (KT)st2.bits, rev = 0;
+        for (uint32_t i = 0; i < run; i++) {
+            uint32_t b = (st2.bits >> (2 * (run - 1 - i))) & 3u;
+            rev = (rev >> 2) | ((KT)(3u - b) << top);
+        }
+        uint64_t seq_acc = 0, kmer_acc = 0, name_end = 0;
+        const uint64_t pos0 = stream_off + base + (uint64_t)threadIdx.x * PIECE;
+        auto flush_rec = [&]() {
+            if (rec && rec <= recs_cap) {
+                if (seq_acc) atomicAdd((unsigned long long *)&recs[rec - 1].seq_len, (unsigned long long)seq_acc);
+                if (kmer_acc) atomicAdd((unsigned long long *)&recs[rec - 1].n_valid, (unsigned long long)kmer_acc);
+                if (name_end) atomicMax((unsigned long long *)&recs[rec - 1].name_end, (unsigned long long)name_end);
+            }
+            if (rec) { seq_tot += seq_acc; kmer_tot += kmer_acc; }
+            seq_acc = 0; kmer_acc = 0; name_end = 0;
+        };
+
+        REC0 *region = flat + ((uint64_t)c * (WG / 64) + wave) * SUB;
+        uint32_t wcount = 0;                               // wave-uniform
+        KT a0 = 0, a1 = 0, a2 = 0, a3 = 0;                 // last four distinct canonical k-mers of this lane
+        uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;           // ... and how often each was seen
+        // wave-uniform call: ballot-compact this step's records into the wave's region (coalesced store)
+        auto wave_emit = [&](bool e, KT a) {
+            unsigned long long m = __ballot(e);
+            if (e) {
+                uint32_t p = wcount + __popcll(m & ((1ull << lane) - 1ull));
+                region[p] = (REC0)a;
+                atomicAdd(&hist1[(uint32_t)((uint64_t)a >> shift1)], 1u);
+            }
+            wcount += __popcll(m);
+        };
+        const uint8_t *mine = lds + threadIdx.x * LDS_STRIDE;
+#pragma unroll 1
+        for (int q = 0; q < PIECE / 16; q++) {
+            uint4 v = *reinterpret_cast<const uint4 *>(mine + q * 16);
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint32_t i = q * 16 + j;
+                const uint32_t ch = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                bool has = false;
+                KT canon = 0;
+                if (i < nb) {
+                    if (is_term(ch)) { pend = 0; ls = LS_START; }
+                    else {
+                        bool ws = is_ws(ch), seqchar = false;
+                        if (ls == LS_START) {
+                            if (!ws) {
+                                if (ch == '>') {
+                                    flush_rec();
+                                    rec++;
+                                    if (rec <= recs_cap) recs[rec - 1].name_off = pos0 + i + 1;
+                                    name_end = pos0 + i + 1;
+                                    run = 0;
+                                    ls = LS_HEADER;
+                                } else { ls = LS_SEQ; seqchar = true; }
+                            }
+                        } else if (ls == LS_HEADER) {
+                            if (!ws) name_end = pos0 + i + 1;
+                        } else if (ws) pend++;
+                        else seqchar = true;
+                        if (seqchar) {
+                            if (pend) { seq_acc += pend; run = 0; pend = 0; }
+                            seq_acc++;
+                            uint32_t code = base_code(ch);
+                            if (code > 3u) run = 0;
+                            else {
+                                fwd = (KT)(((fwd << 2) | (KT)code) & mask);
+                                rev = (KT)((rev >> 2) | ((KT)(3u - code) << top));
+                                if (run < k) run++;
+                                if (run == k && rec) { has = true; canon = fwd < rev ? fwd : rev; kmer_acc++; }
+                            }
+                        }
+                    }
+                }
+                // lane-local run merging: only k-mers seen once in the last four distinct ones are emitted
+                bool emit = false;
+                KT ea = 0;
+                if (has) {
+                    if (c0 && canon == a0) c0++;
+                    else if (c1 && canon == a1) c1++;
+                    else if (c2 && canon == a2) c2++;
+                    else if (c3 && canon == a3) c3++;
+                    else {
+                        if (c3 == 1u) { emit = true; ea = a3; }
+                        else if (c3 >= 2u) hot_insert(hot, (uint64_t)a3, c3, side, side_n, side_cap);
+                        a3 = a2; c3 = c2; a2 = a1; c2 = c1; a1 = a0; c1 = c0; a0 = canon; c0 = 1u;
+                    }
+                }
+                wave_emit(emit, ea);
+            }
+        }
+        // drain the lane caches (oldest first)
+        {
+            KT fa[4] = {a3, a2, a1, a0};
+            uint32_t fc[4] = {c3, c2, c1, c0};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (fc[e] >= 2u) hot_insert(hot, (uint64_t)fa[e], fc[e], side, side_n, side_cap);
+                wave_emit(fc[e] == 1u, fa[e]);
+            }
+        }
+        flush_rec();
+        if (lane == 0) cnt[c * (WG / 64) + wave] = wcount;
+        __syncthreads();                                   // pieces consumed; LDS may be restaged
+        if (hot.used >= HOT_SLOTS / 2) hot_flush(hot, side, side_n, side_cap);   // uniform: read after the barrier
+    }
+    hot_flush(hot, side, side_n, side_cap);
+    for (int d = 32; d; d >>= 1) {
+        seq_tot += __shfl_down((unsigned long long)seq_tot, d, 64);
+        kmer_tot += __shfl_down((unsigned long long)kmer_tot, d, 64);
+    }
+    if (lane == 0) {
+        if (seq_tot) atomicAdd((unsigned long long *)&carry->total_bp, (unsigned long long)seq_tot);
+        if (kmer_tot) atomicAdd((unsigned long long *)&carry->num_kmers, (unsigned long long)kmer_tot);
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < pl.B1; d += WG) hist1_rows[(uint64_t)blockIdx.x * pl.B1 + d] = hist1[d];
+}
+
+// ------------------------------------------------------------------ K1: level-1 column scan -----
+// One workgroup, one thread per digit.  rowoff[w][d] = records of digit d written by rows < w;
+// bucket_base[d] = start of bucket d; level-2 rows: bucket d gets ceil(n_d / R2) workgroups.
+__global__ __launch_bounds__(512) void k_rows1_scan(const uint32_t *__restrict__ hist_rows, uint32_t *__restrict__ rowoff, PartPlan pl,
+                                                    uint32_t *__restrict__ bucket_base, uint32_t *__restrict__ wg2_start,
+                                                    uint32_t *__restrict__ final_start) {
+    __shared__ uint32_t tot[512];
+    const uint32_t d = threadIdx.x;
+    uint32_t acc = 0;
+    if (d < pl.B1)
+        for (uint32_t w = 0; w < pl.n_wg0; w++) {
+            uint32_t v = hist_rows[(uint64_t)w * pl.B1 + d];
+            rowoff[(uint64_t)w * pl.B1 + d] = acc;
+            acc += v;
+        }
+    tot[d] = d < pl.B1 ? acc : 0;
+    __syncthreads();
+    if (d == 0) {
+        uint32_t a = 0, wgs = 0;
+        for (uint32_t i = 0; i < pl.B1; i++) {
+            uint32_t n = tot[i];
+            bucket_base[i] = a;
+            wg2_start[i] = wgs;
+            if (pl.b2 == 0) final_start[i] = a;
+            a += n;
+            wgs += (uint32_t)((n + pl.R2 - 1) / pl.R2);
+        }
+        bucket_base[pl.B1] = a;
+        wg2_start[pl.B1] = wgs;
+        if (pl.b2 == 0) final_start[pl.B1] = a;
+    }
+}
+
+// ------------------------------------------------------------------ K2 / K5: scatter ------------
+// One tile = up to 16384 records: rank within digit by LDS atomic, exclusive scan of the digit
+// counts, records + digits parked in LDS in sorted order, then written as coalesced runs at
+// run[d] (this workgroup's running output offset for digit d).
+struct ScatterLds {
+    uint32_t rec[TILE];
+    uint16_t dig[TILE];
+    uint32_t hist[512], off[512], run[512], gbase[512];
+    uint32_t wsum[SC_T / 64];
+};
+
+template <typename RIN>
+__device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PER], const bool (&ok)[SC_PER], uint32_t n_tile,
+                                             uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out) {
+    uint32_t dg[SC_PER], rk[SC_PER];
+#pragma unroll
+    for (int j = 0; j < SC_PER; j++) {
+        dg[j] = 0; rk[j] = 0;
+        if (ok[j]) {
+            dg[j] = (uint32_t)((uint64_t)r[j] >> shift) & (B - 1u);
+            rk[j] = atomicAdd(&L.hist[dg[j]], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of hist[0..B) by the first B threads (B <= 512 <= SC_T)
+    {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        uint32_t v = threadIdx.x < B ? L.hist[threadIdx.x] : 0u, inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63) L.wsum[w] = inc;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (int i = 0; i < w; i++) pre += L.wsum[i];
+        if (threadIdx.x < B) {
+            L.off[threadIdx.x] = pre + inc - v;
+            L.gbase[threadIdx.x] = L.run[threadIdx.x];
+            L.run[threadIdx.x] += v;
+            L.hist[threadIdx.x] = 0;                          // ready for the next tile
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SC_PER; j++)
+        if (ok[j]) {
+            uint32_t p = L.off[dg[j]] + rk[j];
+            L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask);
+            L.dig[p] = (uint16_t)dg[j];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SC_PER; j++) {
+        uint32_t p = threadIdx.x + j * SC_T;
+        if (p < n_tile) {
+            uint32_t d = L.dig[p];
+            uint32_t dst = L.gbase[d] + (p - L.off[d]);
+            if (out16) reinterpret_cast<uint16_t *>(out)[dst] = (uint16_t)L.rec[p];
+            else reinterpret_cast<uint32_t *>(out)[dst] = L.rec[p];
+        }
+    }
+    __syncthreads();
+}
+
+// level 1: source = the flat (chunk, wave) regions written by k_walk_flat; workgroup w owns the same
+// chunk range as walk workgroup w, so its row of offsets applies.
+template <typename REC0>
+__global__ __launch_bounds__(SC_T) void k_scatter1(const REC0 *__restrict__ flat, const uint32_t *__restrict__ cnt,
+                                                   const uint32_t *__restrict__ rowoff, const uint32_t *__restrict__ bucket_base,
+                                                   PartPlan pl, void *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    ScatterLds &L = *reinterpret_cast<ScatterLds *>(smem);
+    const uint32_t B = pl.B1, shift = pl.addr_bits - pl.b1;
+    const uint32_t low_mask = shift >= 32 ? 0xffffffffu : ((1u << shift) - 1u);
+    const bool out16 = pl.b2 == 0;
+    if (threadIdx.x < 512) { L.hist[threadIdx.x] = 0; L.run[threadIdx.x] = 0; }
+    __syncthreads();
+    if (threadIdx.x < B) L.run[threadIdx.x] = bucket_base[threadIdx.x] + rowoff[(uint64_t)blockIdx.x * B + threadIdx.x];
+    __syncthreads();
+    const uint32_t c_lo = blockIdx.x * pl.G, c_hi = min(c_lo + pl.G, pl.n_chunks);
+    for (uint32_t c = c_lo; c < c_hi; c++) {
+        const uint32_t n0 = cnt[c * 4 + 0], n1 = cnt[c * 4 + 1], n2 = cnt[c * 4 + 2], n3 = cnt[c * 4 + 3];
+        const uint32_t p1 = n0, p2 = n0 + n1, p3 = p2 + n2, n_tile = p3 + n3;
+        if (n_tile == 0) continue;
+        const REC0 *src = flat + (uint64_t)c * 4 * SUB;
+        REC0 r[SC_PER];
+        bool ok[SC_PER];
+#pragma unroll
+        for (int j = 0; j < SC_PER; j++) {
+            uint32_t i = threadIdx.x + j * SC_T;
+            ok[j] = i < n_tile;
+            r[j] = 0;
+            if (ok[j]) {
+                uint32_t s = (i >= p1) + (i >= p2) + (i >= p3);
+                uint32_t pre = s == 0 ? 0u : s == 1 ? p1 : s == 2 ? p2 : p3;
+                r[j] = src[s * SUB + (i - pre)];
+            }
+        }
+        scatter_tile<REC0>(L, r, ok, n_tile, shift, B, low_mask, out16, out);
+    }
+}
+
+// level-2 work split: bucket b is covered by workgroups wg2_start[b] .. wg2_start[b+1]-1, R2 records each
+__device__ __forceinline__ bool wg2_range(const uint32_t *__restrict__ wg2_start, const uint32_t *__restrict__ bucket_base,
+                                          const PartPlan &pl, uint32_t &b, uint32_t &lo, uint32_t &hi) {
+    const uint32_t w = blockIdx.x;
+    if (w >= wg2_start[pl.B1]) return false;
+    uint32_t a = 0, z = pl.B1;                              // last b with wg2_start[b] <= w
+    while (z - a > 1) { uint32_t m = (a + z) >> 1; if (wg2_start[m] <= w) a = m; else z = m; }
+    b = a;
+    uint64_t s = (uint64_t)bucket_base[b] + (uint64_t)(w - wg2_start[b]) * pl.R2;
+    uint64_t e = s + pl.R2;
+    if (e > bucket_base[b + 1]) e = bucket_base[b + 1];
+    lo = (uint32_t)s; hi = (uint32_t)e;
+    return true;
+}
+
+__global__ __launch_bounds__(WG) void k_count2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ wg2_start,
+                                               const uint32_t *__restrict__ bucket_base, PartPlan pl, uint32_t *__restrict__ hist_rows) {
+    __shared__ uint32_t h[512];
+    for (uint32_t d = threadIdx.x; d < pl.B2; d += WG) h[d] = 0;
+    __syncthreads();
+    uint32_t b, lo, hi;
+    const bool live = wg2_range(wg2_start, bucket_base, pl, b, lo, hi);
+    const uint32_t shift = pl.fb_bits;
+    if (live)
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += WG) atomicAdd(&h[(in[i] >> shift) & (pl.B2 - 1u)], 1u);
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < pl.B2; d += WG) hist_rows[(uint64_t)blockIdx.x * pl.B2 + d] = live ? h[d] : 0u;
+}
+
+// K4: one workgroup per level-1 bucket, one thread per level-2 digit.
+__global__ __launch_bounds__(512) void k_rows2_scan(const uint32_t *__restrict__ hist_rows, uint32_t *__restrict__ rowoff,
+                                                    const uint32_t *__restrict__ wg2_start, const uint32_t *__restrict__ bucket_base,
+                                                    PartPlan pl, uint32_t *__restrict__ final_start) {
+    __shared__ uint32_t tot[512];
+    const uint32_t b = blockIdx.x, d = threadIdx.x;
+    uint32_t acc = 0;
+    if (d < pl.B2)
+        for (uint32_t w = wg2_start[b]; w < wg2_start[b + 1]; w++) {
+            uint32_t v = hist_rows[(uint64_t)w * pl.B2 + d];
+            rowoff[(uint64_t)w * pl.B2 + d] = acc;
+            acc += v;
+        }
+    tot[d] = d < pl.B2 ? acc : 0;
+    __syncthreads();
+    if (d == 0) {
+        uint32_t a = bucket_base[b];
+        for (uint32_t i = 0; i < pl.B2; i++) { uint32_t n = tot[i]; final_start[(uint64_t)b * pl.B2 + i] = a; a += n; }
+        if (b == pl.B1 - 1) final_start[(uint64_t)pl.B1 * pl.B2] = a;
+    }
+}
+
+__global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ wg2_start,
+                                                   const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ rowoff,
+                                                   const uint32_t *__restrict__ final_start, PartPlan pl, void *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    ScatterLds &L = *reinterpret_cast<ScatterLds *>(smem);
+    uint32_t b, lo, hi;
+    if (!wg2_range(wg2_start, bucket_base, pl, b, lo, hi)) return;      // uniform per workgroup
+    const uint32_t B = pl.B2, shift = pl.fb_bits;
+    const uint32_t low_mask = (1u << shift) - 1u;
+    if (threadIdx.x < 512) { L.hist[threadIdx.x] = 0; L.run[threadIdx.x] = 0; }
+    __syncthreads();
+    if (threadIdx.x < B) L.run[threadIdx.x] = final_start[(uint64_t)b * B + threadIdx.x] + rowoff[(uint64_t)blockIdx.x * B + threadIdx.x];
+    __syncthreads();
+    for (uint32_t t0 = lo; t0 < hi; t0 += TILE) {
+        const uint32_t n_tile = min((uint32_t)TILE, hi - t0);
+        uint32_t r[SC_PER];
+        bool ok[SC_PER];
+#pragma unroll
+        for (int j = 0; j < SC_PER; j++) {
+            uint32_t i = threadIdx.x + j * SC_T;
+            ok[j] = i < n_tile;
+            r[j] = ok[j] ? in[t0 + i] : 0u;
+        }
+        scatter_tile<uint32_t>(L, r, ok, n_tile, shift, B, low_mask, true, out);
+    }
+}
+
+// ------------------------------------------------------------------ K6: count in LDS ------------
+// One workgroup per final bucket (2^fb_bits addresses, fb_bits <= 16).  Counters are 16 bit, two per
+// LDS dword; a bucket with more than 65024 records is folded in pieces with a clamp between them so a
+// counter (<= 255 + 65024) can never carry into its neighbour.
+constexpr uint32_t K6_PIECE = 65024;   // multiple of 8
+
+__global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
+                                                       uint32_t fb_bits, uint8_t *__restrict__ table8) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);                  // 2^fb_bits / 2 dwords
+    const uint32_t fb = blockIdx.x;
+    const uint32_t start = final_start[fb], end = final_start[fb + 1];
+    if (start == end) return;                                            // slice untouched
+    const uint32_t n_addr = 1u << fb_bits;
+    uint8_t *slice = table8 + (uint64_t)fb * n_addr;
+    // fold in what the slice already holds (earlier feeds); slices are >= 16 bytes except at k = 1
+    if (n_addr >= 16) {
+        for (uint32_t g = threadIdx.x; g < n_addr / 16; g += SC_T) {
+            uint4 v = reinterpret_cast<const uint4 *>(slice)[g];
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                uint32_t lo = (w[q >> 1] >> (16 * (q & 1))) & 0xffu, hi = (w[q >> 1] >> (16 * (q & 1) + 8)) & 0xffu;
+                cnt[g * 8 + q] = lo | (hi << 16);
+            }
+        }
+    } else {
+        for (uint32_t a = threadIdx.x; a < n_addr / 2; a += SC_T) cnt[a] = (uint32_t)slice[2 * a] | ((uint32_t)slice[2 * a + 1] << 16);
+    }
+    __syncthreads();
+    const uint32_t base = start & ~7u;                                   // 16-byte aligned vector loads
+    for (uint32_t p0 = base; p0 < end; p0 += K6_PIECE) {
+        const uint32_t p1 = min(p0 + K6_PIECE, end);
+        for (uint32_t i = p0 + threadIdx.x * 8; i < p1; i += SC_T * 8) {
+            uint4 v = *reinterpret_cast<const uint4 *>(recs + i);
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                uint32_t idx = i + q;
+                if (idx >= start && idx < end) {
+                    uint32_t a = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                    atomicAdd(&cnt[a >> 1], 1u << (16 * (a & 1)));
+                }
+            }
+        }
+        __syncthreads();
+        if (p1 < end) {                                                  // more to come: clamp so nothing can overflow
+            for (uint32_t a = threadIdx.x; a < max(n_addr / 2, 1u); a += SC_T) {
+                uint32_t x = cnt[a], lo = x & 0xffffu, hi = x >> 16;
+                cnt[a] = (lo > 255u ? 255u : lo) | ((hi > 255u ? 255u : hi) << 16);
+            }
+            __syncthreads();
+        }
+    }
+    // clamp to u8 and write the slice back, 16 addresses per lane
+    if (n_addr >= 16) {
+        for (uint32_t g = threadIdx.x; g < n_addr / 16; g += SC_T) {
+            uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                uint32_t x = cnt[g * 8 + q], lo = x & 0xffffu, hi = x >> 16;
+                lo = lo > 255u ? 255u : lo; hi = hi > 255u ? 255u : hi;
+                o[q >> 1] |= (lo | (hi << 8)) << (16 * (q & 1));
+            }
+            reinterpret_cast<uint4 *>(slice)[g] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    } else {
+        for (uint32_t a = threadIdx.x; a < n_addr / 2; a += SC_T) {
+            uint32_t x = cnt[a], lo = x & 0xffffu, hi = x >> 16;
+            slice[2 * a] = (uint8_t)(lo > 255u ? 255u : lo);
+            slice[2 * a + 1] = (uint8_t)(hi > 255u ? 255u : hi);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K7: fold the side list in ---
+// Side entries (addr, count) from the hot-key tables: aggregated once more per workgroup in LDS, then
+// added to the finished u8 table with a saturating compare-and-swap on the containing dword.
+constexpr uint32_t AS_SLOTS = 4096, AS_WGS = 64;
+
+__device__ __forceinline__ void table_sat_add(uint8_t *table8, uint64_t addr, uint32_t cnt) {
+    unsigned int *word = reinterpret_cast<unsigned int *>(table8 + (addr & ~3ull));
+    const uint32_t sh = (uint32_t)(addr & 3ull) * 8u;
+    unsigned int old = *word;
+    while (true) {
+        uint32_t b = (old >> sh) & 0xffu;
+        uint32_t nb = b + cnt > 255u ? 255u : b + cnt;
+        if (nb == b) return;
+        unsigned int want = (old & ~(0xffu << sh)) | (nb << sh);
+        unsigned int prev = atomicCAS(word, old, want);
+        if (prev == old) return;
+        old = prev;
+    }
+}
+
+__global__ __launch_bounds__(WG) void k_apply_side(const unsigned long long *__restrict__ side, const unsigned long long *__restrict__ side_n,
+                                                   uint64_t side_cap, uint8_t *__restrict__ table8) {
+    __shared__ unsigned long long key[AS_SLOTS];
+    __shared__ uint32_t val[AS_SLOTS];
+    unsigned long long n = *side_n;
+    if (n > side_cap) n = side_cap;
+    const unsigned long long per = (n + gridDim.x - 1) / gridDim.x;
+    const unsigned long long lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+    if (lo >= hi) return;
+    for (uint32_t i = threadIdx.x; i < AS_SLOTS; i += WG) { key[i] = 0ull; val[i] = 0u; }
+    __syncthreads();
+    for (unsigned long long i = lo + threadIdx.x; i < hi; i += WG) {
+        const unsigned long long e = side[i];
+        const uint64_t addr = e >> SIDE_CNT_BITS;
+        const uint32_t cnt = (uint32_t)(e & ((1ull << SIDE_CNT_BITS) - 1ull));
+        const unsigned long long kk = addr + 1ull;
+        uint32_t h = (uint32_t)((addr * 0x9E3779B97F4A7C15ull) >> 40) & (AS_SLOTS - 1u);
+        bool done = false;
+        for (uint32_t t = 0; t < 32 && !done; t++) {
+            unsigned long long old = atomicCAS(&key[h], 0ull, kk);
+            if (old == 0ull || old == kk) {
+                uint32_t before = atomicAdd(&val[h], cnt);
+                if (before + cnt < before) atomicExch(&val[h], 0xffffffffu);      // saturate instead of wrapping
+                done = true;
+            }
+            h = (h + 1u) & (AS_SLOTS - 1u);
+        }
+        if (!done) table_sat_add(table8, addr, cnt > 255u ? 255u : cnt);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < AS_SLOTS; i += WG)
+        if (key[i] != 0ull) table_sat_add(table8, key[i] - 1ull, val[i] > 255u ? 255u : val[i]);
+}
+
+// ------------------------------------------------------------------ plan + launch sequence ------
+PartPlan make_part_plan(uint32_t k, uint64_t n_bytes) {
+    PartPlan pl;
+    pl.k = k;
+    pl.addr_bits = 2 * k;
+    pl.fb_bits = pl.addr_bits < 16 ? pl.addr_bits : 16;
+    const uint32_t bucket_bits = pl.addr_bits - pl.fb_bits;
+    pl.b1 = bucket_bits <= 9 ? bucket_bits : (bucket_bits + 1) / 2;
+    pl.b2 = bucket_bits - pl.b1;
+    pl.B1 = 1u << pl.b1;
+    pl.B2 = 1u << pl.b2;
+    pl.n_chunks = (uint32_t)((n_bytes + CHUNK - 1) / CHUNK);
+    pl.n_wg0 = pl.n_chunks < 1024u ? pl.n_chunks : 1024u;
+    if (pl.n_wg0 == 0) pl.n_wg0 = 1;
+    pl.G = (pl.n_chunks + pl.n_wg0 - 1) / pl.n_wg0;
+    if (pl.G == 0) pl.G = 1;
+    uint64_t r2 = (n_bytes + 1023) / 1024;
+    pl.R2 = r2 < (uint64_t)TILE ? (uint64_t)TILE : ((r2 + TILE - 1) / TILE) * TILE;
+    pl.n_wg2_max = (uint32_t)(n_bytes / pl.R2) + pl.B1 + 1;
+    return pl;
+}
+
+size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace *lay) {
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t rec0 = pl.k > 15 ? 8 : 4;
+    const uint64_t nfb = (uint64_t)pl.B1 * pl.B2;
+    size_t o = 0;
+    lay->flat = o; o += up((size_t)pl.n_chunks * 4 * SUB * rec0);
+    lay->cnt = o; o += up((size_t)pl.n_chunks * 4 * 4);
+    lay->hist1 = o; o += up((size_t)pl.n_wg0 * pl.B1 * 4);
+    lay->rowoff1 = o; o += up((size_t)pl.n_wg0 * pl.B1 * 4);
+    lay->bucket_base = o; o += up((size_t)(pl.B1 + 1) * 4);
+    lay->wg2_start = o; o += up((size_t)(pl.B1 + 1) * 4);
+    lay->final_start = o; o += up((size_t)(nfb + 1) * 4);
+    lay->out1 = o; o += up((size_t)(n_bytes + 64) * (pl.b2 ? 4 : 2));
+    lay->hist2 = o; o += up((size_t)pl.n_wg2_max * pl.B2 * 4);
+    lay->rowoff2 = o; o += up((size_t)pl.n_wg2_max * pl.B2 * 4);
+    lay->out2 = o; o += up(pl.b2 ? (size_t)(n_bytes + 64) * 2 : 256);
+    lay->side_cap = n_bytes / 2 + 16;                      // every side entry stands for >= 2 k-mers
+    lay->side = o; o += up((size_t)lay->side_cap * 8);
+    lay->side_n = o; o += 256;
+    return o;
+}
+
+int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const L1 *st1, const L2 *st2, const PartPlan &pl,
+                       uint8_t *ws, const PartWorkspace &lay, uint8_t *table8, DevRec *recs, uint64_t recs_cap, Carry *carry,
+                       hipStream_t s, hipEvent_t ev_walk_end, hipEvent_t ev_part_end) {
+    uint32_t *cnt = (uint32_t *)(ws + lay.cnt), *hist1 = (uint32_t *)(ws + lay.hist1), *rowoff1 = (uint32_t *)(ws + lay.rowoff1);
+    uint32_t *bucket_base = (uint32_t *)(ws + lay.bucket_base), *wg2_start = (uint32_t *)(ws + lay.wg2_start);
+    uint32_t *final_start = (uint32_t *)(ws + lay.final_start), *hist2 = (uint32_t *)(ws + lay.hist2), *rowoff2 = (uint32_t *)(ws + lay.rowoff2);
+    void *flat = ws + lay.flat, *out1 = ws + lay.out1, *out2 = ws + lay.out2;
+    unsigned long long *side = (unsigned long long *)(ws + lay.side), *side_n = (unsigned long long *)(ws + lay.side_n);
+    hipFuncSetAttribute((const void *)k_scatter1<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds));
+    hipFuncSetAttribute((const void *)k_scatter1<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds));
+    hipFuncSetAttribute((const void *)k_scatter2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds));
+    hipFuncSetAttribute((const void *)k_bucket_count, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (hipMemsetAsync(side_n, 0, 8, s) != hipSuccess) return -2;
+    if (pl.k <= 15) {
+        hipLaunchKernelGGL((k_walk_flat<uint32_t, uint32_t>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, st1, st2, pl,
+                           (uint32_t *)flat, cnt, hist1, recs, recs_cap, carry, side, side_n, lay.side_cap);
+    } else {
+        hipLaunchKernelGGL((k_walk_flat<uint64_t, uint64_t>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, st1, st2, pl,
+                           (uint64_t *)flat, cnt, hist1, recs, recs_cap, carry, side, side_n, lay.side_cap);
+    }
+    if (ev_walk_end) hipEventRecord(ev_walk_end, s);
+    hipLaunchKernelGGL(k_rows1_scan, dim3(1), dim3(512), 0, s, hist1, rowoff1, pl, bucket_base, wg2_start, final_start);
+    if (pl.k <= 15)
+        hipLaunchKernelGGL(k_scatter1<uint32_t>, dim3(pl.n_wg0), dim3(SC_T), sizeof(ScatterLds), s, (const uint32_t *)flat, cnt, rowoff1,
+                           bucket_base, pl, out1);
+    else
+        hipLaunchKernelGGL(k_scatter1<uint64_t>, dim3(pl.n_wg0), dim3(SC_T), sizeof(ScatterLds), s, (const uint64_t *)flat, cnt, rowoff1,
+                           bucket_base, pl, out1);
+    const uint16_t *final_recs = (const uint16_t *)out1;
+    if (pl.b2) {
+        hipLaunchKernelGGL(k_count2, dim3(pl.n_wg2_max), dim3(WG), 0, s, (const uint32_t *)out1, wg2_start, bucket_base, pl, hist2);
+        hipLaunchKernelGGL(k_rows2_scan, dim3(pl.B1), dim3(512), 0, s, hist2, rowoff2, wg2_start, bucket_base, pl, final_start);
+        hipLaunchKernelGGL(k_scatter2, dim3(pl.n_wg2_max), dim3(SC_T), sizeof(ScatterLds), s, (const uint32_t *)out1, wg2_start,
+                           bucket_base, rowoff2, final_start, pl, out2);
+        final_recs = (const uint16_t *)out2;
+    }
+    if (ev_part_end) hipEventRecord(ev_part_end, s);
+    const uint32_t nfb = pl.B1 * pl.B2;
+    const size_t lds6 = ((size_t)1 << pl.fb_bits) * 2 < 64 ? 64 : ((size_t)1 << pl.fb_bits) * 2;
+    hipLaunchKernelGGL(k_bucket_count, dim3(nfb), dim3(SC_T), lds6, s, final_recs, final_start, pl.fb_bits, table8);
+    hipLaunchKernelGGL(k_apply_side, dim3(AS_WGS), dim3(WG), 0, s, side, side_n, lay.side_cap, table8);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // namespace pk

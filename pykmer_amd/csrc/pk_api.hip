@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -71,15 +72,19 @@ struct pk_indexer {
     uint64_t staging_cap = 0;
     uint64_t bytes_fed = 0, since_clamp = 0, n_recs = 0;
     bool finished = false;
-    hipEvent_t ev[8] = {};
-    double t_scan = 0, t_count = 0, t_final = 0, t_zero = 0;
+    hipEvent_t ev[12] = {};
+    double t_scan = 0, t_count = 0, t_final = 0, t_zero = 0, t_part = 0, t_bucket = 0;
     int count_launches = 0;
+    bool direct = false;             // PK_COUNT_MODE=direct: version-1 table update (global atomics on u32 counters)
+    uint8_t *ws = nullptr;           // partitioned mode workspace
+    size_t ws_cap = 0;
 };
 
 static int ix_reset(pk_indexer *ix) {
     HIPCHK(hipSetDevice(ix->device));
     HIPCHK(hipEventRecord(ix->ev[6], ix->stream));
-    HIPCHK(hipMemsetAsync(ix->table32, 0, ix->n * sizeof(uint32_t), ix->stream));
+    if (ix->direct) HIPCHK(hipMemsetAsync(ix->table32, 0, ix->n * sizeof(uint32_t), ix->stream));
+    else HIPCHK(hipMemsetAsync(ix->table8, 0, std::max<uint64_t>(ix->n, 16), ix->stream));
     HIPCHK(hipEventRecord(ix->ev[7], ix->stream));
     Carry c;
     memset(&c, 0, sizeof c);
@@ -94,7 +99,7 @@ static int ix_reset(pk_indexer *ix) {
     ix->t_zero = ms * 1e-3;
     ix->bytes_fed = ix->since_clamp = ix->n_recs = 0;
     ix->finished = false;
-    ix->t_scan = ix->t_count = ix->t_final = 0;
+    ix->t_scan = ix->t_count = ix->t_final = ix->t_part = ix->t_bucket = 0;
     ix->count_launches = 0;
     return PK_OK;
 }
@@ -104,7 +109,7 @@ extern "C" void pk_indexer_destroy(pk_indexer *ix) {
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
     hipFree(ix->table32); hipFree(ix->table8); hipFree(ix->carry); hipFree(ix->hist); hipFree(ix->recs);
-    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->staging);
+    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->staging); hipFree(ix->ws);
     for (auto &e : ix->ev) if (e) hipEventDestroy(e);
     if (ix->stream) hipStreamDestroy(ix->stream);
     delete ix;
@@ -128,7 +133,9 @@ extern "C" int pk_indexer_create(pk_indexer **out, int k, int device) {
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     for (auto &ev : ix->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
-    if ((e = hipMalloc(&ix->table32, ix->n * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(u32 table)");
+    const char *mode = getenv("PK_COUNT_MODE");
+    ix->direct = mode && strcmp(mode, "direct") == 0;
+    if (ix->direct && (e = hipMalloc(&ix->table32, ix->n * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(u32 table)");
     if ((e = hipMalloc(&ix->table8, std::max<uint64_t>(ix->n, 16))) != hipSuccess) return bail(e, "hipMalloc(u8 table)");
     if ((e = hipMalloc(&ix->carry, sizeof(Carry))) != hipSuccess) return bail(e, "hipMalloc(carry)");
     if ((e = hipMalloc(&ix->hist, 256 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(hist)");
@@ -176,9 +183,9 @@ extern "C" int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uin
     if (!dev_fasta || ((uintptr_t)dev_fasta & 15u)) return fail(PK_ERR_ARG, "device FASTA pointer must be non-null and 16-byte aligned");
     if (n_bytes > (1ULL << 40)) return fail(PK_ERR_ARG, "feed of %llu bytes too large; split it", (unsigned long long)n_bytes);
     HIPCHK(hipSetDevice(ix->device));
-    // u32 counters: clamp before any single address could wrap (one k-mer per byte at most)
-    if (ix->since_clamp + n_bytes >= 0xFFFFFF00ULL) {
-        if (n_bytes >= 0xFFFFFF00ULL) return fail(PK_ERR_ARG, "single feed must stay below 4 GiB");
+    if (n_bytes >= 0xFFFFFF00ULL) return fail(PK_ERR_ARG, "single feed must stay below 4 GiB");
+    // direct mode, u32 counters: clamp before any single address could wrap (one k-mer per byte at most)
+    if (ix->direct && ix->since_clamp + n_bytes >= 0xFFFFFF00ULL) {
         launch_clamp32(ix->table32, ix->n, ix->stream);
         ix->since_clamp = 0;
     }
@@ -198,16 +205,35 @@ extern "C" int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uin
     rc = ensure_recs(ix, n_recs);
     if (rc) return rc;
     ix->n_recs = n_recs;
-    HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
-    launch_count(f, n_bytes, ix->bytes_fed, ix->c_l1s, ix->c_l2s, n_chunks, (uint32_t)ix->k, ix->table32, ix->recs, ix->recs_cap,
-                 ix->carry, ix->stream);
-    HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    float a = 0, b = 0;
+    float a = 0, b = 0, c = 0, d = 0;
+    if (ix->direct) {
+        HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
+        launch_count(f, n_bytes, ix->bytes_fed, ix->c_l1s, ix->c_l2s, n_chunks, (uint32_t)ix->k, ix->table32, ix->recs, ix->recs_cap,
+                     ix->carry, ix->stream);
+        HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ix->stream));
+    } else {
+        PartPlan pl = make_part_plan((uint32_t)ix->k, n_bytes);
+        PartWorkspace lay;
+        size_t need = part_workspace_bytes(pl, n_bytes, &lay);
+        if (need > ix->ws_cap) {
+            hipFree(ix->ws); ix->ws = nullptr; ix->ws_cap = 0;
+            HIPCHK(hipMalloc(&ix->ws, need));
+            ix->ws_cap = need;
+        }
+        HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
+        if (launch_partitioned(f, n_bytes, ix->bytes_fed, ix->c_l1s, ix->c_l2s, pl, ix->ws, lay, ix->table8, ix->recs, ix->recs_cap,
+                               ix->carry, ix->stream, ix->ev[3], ix->ev[8]))
+            return fail(PK_ERR_HIP, "partition pipeline launch failed: %s", hipGetErrorString(hipGetLastError()));
+        HIPCHK(hipEventRecord(ix->ev[9], ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        HIPCHK(hipEventElapsedTime(&c, ix->ev[3], ix->ev[8]));
+        HIPCHK(hipEventElapsedTime(&d, ix->ev[8], ix->ev[9]));
+    }
     HIPCHK(hipEventElapsedTime(&a, ix->ev[0], ix->ev[1]));
     HIPCHK(hipEventElapsedTime(&b, ix->ev[2], ix->ev[3]));
-    ix->t_scan += a * 1e-3; ix->t_count += b * 1e-3; ix->count_launches++;
+    ix->t_scan += a * 1e-3; ix->t_count += b * 1e-3; ix->t_part += c * 1e-3; ix->t_bucket += d * 1e-3; ix->count_launches++;
     ix->bytes_fed += n_bytes; ix->since_clamp += n_bytes;
     return PK_OK;
 }
@@ -238,7 +264,8 @@ extern "C" int pk_indexer_finish(pk_indexer *ix, uint64_t *num_kmers_out, uint64
     HIPCHK(hipSetDevice(ix->device));
     if (!ix->finished) {
         HIPCHK(hipEventRecord(ix->ev[4], ix->stream));
-        launch_finalize(ix->table32, ix->table8, ix->n, ix->hist, ix->stream);
+        if (ix->direct) launch_finalize(ix->table32, ix->table8, ix->n, ix->hist, ix->stream);
+        else launch_hist8(ix->table8, ix->n, ix->hist, ix->stream);
         HIPCHK(hipEventRecord(ix->ev[5], ix->stream));
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ix->stream));
@@ -307,6 +334,7 @@ extern "C" int pk_indexer_timings(pk_indexer *ix, double out[8]) {
     if (!ix || !out) return fail(PK_ERR_ARG, "null argument");
     for (int i = 0; i < 8; i++) out[i] = 0;
     out[0] = ix->t_scan; out[1] = ix->t_count; out[2] = ix->t_final; out[3] = ix->t_zero; out[4] = (double)ix->count_launches;
+    out[5] = ix->t_part; out[6] = ix->t_bucket; out[7] = ix->direct ? 1.0 : 0.0;
     return PK_OK;
 }
 

@@ -35,6 +35,26 @@ void launch_finalize(const uint32_t *table32, uint8_t *table8, uint64_t n, unsig
 void launch_hist8(const uint8_t *table8, uint64_t n, unsigned long long *hist, hipStream_t s);
 void launch_clamp32(uint32_t *table32, uint64_t n, hipStream_t s);
 
+// kmer_part.hip -- partitioned table update (version 2)
+struct PartPlan {
+    uint32_t k, addr_bits;   // 2k
+    uint32_t fb_bits;        // address bits inside a final bucket (<= 16)
+    uint32_t b1, b2, B1, B2; // level-1 / level-2 digit widths and bucket counts
+    uint32_t n_chunks;       // 16 KiB FASTA chunks in this feed
+    uint32_t n_wg0, G;       // walk workgroups and chunks per workgroup (rows of the level-1 histogram)
+    uint64_t R2;             // records per level-2 workgroup
+    uint32_t n_wg2_max;      // upper bound on level-2 workgroups
+};
+struct PartWorkspace {       // byte offsets into one device allocation
+    size_t flat, cnt, hist1, rowoff1, bucket_base, wg2_start, final_start, out1, hist2, rowoff2, out2, side, side_n;
+    uint64_t side_cap;
+};
+PartPlan make_part_plan(uint32_t k, uint64_t n_bytes);
+size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace *lay);
+int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const L1 *st1, const L2 *st2, const PartPlan &pl,
+                       uint8_t *ws, const PartWorkspace &lay, uint8_t *table8, DevRec *recs, uint64_t recs_cap, Carry *carry,
+                       hipStream_t s, hipEvent_t ev_walk_end, hipEvent_t ev_part_end);
+
 // gram_scan.hip
 // tables: device array of N device pointers, each n_slice bytes (16-byte aligned).  pair: device N*N u64,
 // zeroed by the launcher; [i][i] += total_i, [i][j] (i<j) += shared_ij.
