@@ -184,59 +184,64 @@ __device__ __forceinline__ uint32_t piece_len(uint64_t chunk_base, uint64_t n_by
     return left < (uint64_t)PIECE ? (uint32_t)left : (uint32_t)PIECE;
 }
 
-// Walks the lane's piece in LDS calling f(index, byte) for each of its nb bytes.
+// Walks the lane's piece in LDS calling f(index, byte, active) for each of the PIECE byte slots.
+// A ROLLED loop on purpose: the bodies below are 100+ instructions, and unrolling them 64x produced
+// 30k-120k-instruction kernels that thrash the instruction cache (measured: 20x slower).  The trip
+// count is uniform (callers may use wave-wide ballots inside f); `active` is false past the lane's
+// last byte.  16 bytes are fetched per ds_read_b128 and shifted through four registers.
 template <class Fn>
 __device__ __forceinline__ void for_each_byte(const uint8_t *lds, uint32_t nb, Fn &&f) {
     const uint8_t *mine = lds + threadIdx.x * LDS_STRIDE;
-#pragma unroll
-    for (int q = 0; q < PIECE / 16; q++) {
-        if ((uint32_t)(q * 16) >= nb) break;
-        uint4 v = *reinterpret_cast<const uint4 *>(mine + q * 16);
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            uint32_t idx = q * 16 + j;
-            if (idx < nb) f(idx, (w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll 1
+    for (uint32_t i = 0; i < (uint32_t)PIECE; i++) {
+        if ((i & 15u) == 0u) {
+            uint4 v = *reinterpret_cast<const uint4 *>(mine + i);
+            w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w;
+        } else if ((i & 3u) == 0u) {
+            w0 = w1; w1 = w2; w2 = w3;
         }
+        f(i, (w0 >> ((i & 3u) * 8u)) & 0xffu, i < nb);
     }
 }
 
 // L1 summary of the lane's piece.
 __device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb) {
-    if (nb == 0) return 0;
     uint32_t st = LS_START;
     bool ht = false;
-    for_each_byte(lds, nb, [&](uint32_t, uint32_t c) {
-        if (is_term(c)) { st = LS_START; ht = true; }
-        else if (st == LS_START && !is_ws(c)) st = (c == '>') ? LS_HEADER : LS_SEQ;
+    for_each_byte(lds, nb, [&](uint32_t, uint32_t c, bool act) {
+        bool term = act && is_term(c);
+        bool opens = act && st == LS_START && !is_ws(c);
+        st = term ? (uint32_t)LS_START : opens ? (c == '>' ? (uint32_t)LS_HEADER : (uint32_t)LS_SEQ) : st;
+        ht |= term;
     });
-    return l1_make(ht, st);
+    return nb ? l1_make(ht, st) : 0u;
 }
 
 // L2 summary of the lane's piece, given its exact incoming line state.
 __device__ __forceinline__ L2 piece_l2(const uint8_t *lds, uint32_t nb, uint32_t ls_in, uint32_t km1) {
-    if (nb == 0) return l2_identity();
-    uint32_t ls = ls_in, flags = F_NONID, len = 0, bits = 0, rec = 0;
-    uint32_t pt = 0;
+    uint32_t ls = ls_in, flags = F_NONID, len = 0, bits = 0, rec = 0, pt = 0;
     const uint32_t bm = bases_mask(km1);
-    for_each_byte(lds, nb, [&](uint32_t i, uint32_t c) {
-        if (is_term(c)) { ls = LS_START; flags |= F_PRESET; pt = 0; return; }
-        bool ws = is_ws(c);
-        if (ls == LS_START) {
-            if (ws) return;
-            if (c == '>') { ls = LS_HEADER; rec++; flags |= F_BRK; len = 0; bits = 0; return; }
-            ls = LS_SEQ;
-        } else if (ls == LS_HEADER) {
-            return;
-        } else if (ws) { pt++; return; }
-        // sequence character
-        if (i == 0 && ls_in == LS_SEQ) flags |= F_FRONT;
-        if (pt) { flags |= F_BRK; len = 0; bits = 0; }     // whitespace inside the piece became interior
-        flags |= F_PRESET; pt = 0;
-        uint32_t code = base_code(c);
-        if (code < 4u) { bits = ((bits << 2) | code) & bm; if (len < km1) len++; }
-        else { flags |= F_BRK; len = 0; bits = 0; }
+    for_each_byte(lds, nb, [&](uint32_t i, uint32_t c, bool act) {
+        const bool term = is_term(c), ws = is_ws(c), gt = c == '>';
+        const bool at_start = ls == LS_START;
+        const bool hdr_start = act && at_start && !ws && gt;
+        const bool seqchar = act && !ws && (ls == LS_SEQ || (at_start && !gt));
+        const bool seqws = act && ws && !term && ls == LS_SEQ;
+        const bool t = act && term;
+        if (seqchar && i == 0 && ls_in == LS_SEQ) flags |= F_FRONT;
+        const uint32_t code = base_code(c);
+        const bool valid = seqchar && code < 4u;
+        // a break: new record, invalid character, or whitespace inside the piece that turned out interior
+        const bool brk = hdr_start || (seqchar && (code > 3u || pt != 0u));
+        if (brk) { flags |= F_BRK; len = 0; bits = 0; }
+        if (valid) { bits = ((bits << 2) | code) & bm; len = len < km1 ? len + 1 : len; }
+        if (t || seqchar) flags |= F_PRESET;
+        pt = (t || seqchar) ? 0u : pt + (seqws ? 1u : 0u);
+        rec += hdr_start ? 1u : 0u;
+        ls = t ? (uint32_t)LS_START : hdr_start ? (uint32_t)LS_HEADER : seqchar ? (uint32_t)LS_SEQ : ls;
     });
+    if (nb == 0) return l2_identity();
     if (len >= km1) flags |= F_BRK;
     L2 s; s.flags = flags | (len << 8); s.bits = bits; s.rec = rec; s.p_tail = pt;
     return s;

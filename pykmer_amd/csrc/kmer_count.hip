@@ -11,6 +11,7 @@
 // global_atomic_add_u32 per run; k_finalize then clamps to u8, which is exact because the reference
 // only ever keeps min(255, count) (indexer.py:239,262).
 #include "fasta_fsm.h"
+#include "kmer_walk.h"
 #include "pk_kernels.h"
 
 namespace pk {
@@ -125,75 +126,24 @@ __global__ __launch_bounds__(WG) void k_count(const uint8_t *__restrict__ fasta,
     L2 st2 = wg_excl_scan_l2(piece_l2(lds, nb, ls, km1), chunk_l2_state[blockIdx.x], sh2, &tot2, km1);
 
     // exact parser state at this lane's first byte
-    uint64_t pend = st2.p_tail;
-    uint32_t run = l2_len(st2);
-    uint32_t rec = st2.rec;                        // headers seen so far; 0 = before the first record
-    const KT mask = (KT)((k >= sizeof(KT) * 4) ? ~(KT)0 : (((KT)1 << (2 * k)) - 1));
-    const uint32_t top = 2 * km1;
-    KT fwd = (KT)st2.bits, rev = 0;
-    for (uint32_t i = 0; i < run; i++) {           // rebuild the reverse-complement value of the carried bases
-        uint32_t b = (st2.bits >> (2 * (run - 1 - i))) & 3u;
-        rev = (rev >> 2) | ((KT)(3u - b) << top);
-    }
-    uint64_t seq_acc = 0, kmer_acc = 0, seq_tot = 0, kmer_tot = 0, name_end = 0;
-    const uint64_t pos0 = stream_off + base + (uint64_t)threadIdx.x * PIECE;
+    __shared__ RecAcc racc;
+    recacc_init(racc);
+    __syncthreads();
+    recacc_retarget(racc, chunk_l2_state[blockIdx.x].rec, recs, recs_cap);
+    __syncthreads();
+    Walker<KT> wk;
+    wk.setup(k, recs, recs_cap, &racc);
+    wk.begin(ls, st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
     DirectSink sink;
     sink.init(table32);
-
-    auto flush_rec = [&]() {
-        if (rec && rec <= recs_cap) {
-            if (seq_acc) atomicAdd((unsigned long long *)&recs[rec - 1].seq_len, (unsigned long long)seq_acc);
-            if (kmer_acc) atomicAdd((unsigned long long *)&recs[rec - 1].n_valid, (unsigned long long)kmer_acc);
-            if (name_end) atomicMax((unsigned long long *)&recs[rec - 1].name_end, (unsigned long long)name_end);
-        }
-        if (rec) { seq_tot += seq_acc; kmer_tot += kmer_acc; }   // text before the first header belongs to no record
-        seq_acc = 0; kmer_acc = 0; name_end = 0;
-    };
-
-    for_each_byte(lds, nb, [&](uint32_t i, uint32_t c) {
-        if (is_term(c)) { pend = 0; ls = LS_START; return; }
-        bool ws = is_ws(c);
-        if (ls == LS_START) {
-            if (ws) return;
-            if (c == '>') {                                   // indexer.py:66-82: new record
-                flush_rec();
-                rec++;
-                if (rec <= recs_cap) recs[rec - 1].name_off = pos0 + i + 1;
-                name_end = pos0 + i + 1;
-                run = 0;
-                ls = LS_HEADER;
-                return;
-            }
-            ls = LS_SEQ;
-        } else if (ls == LS_HEADER) {
-            if (!ws) name_end = pos0 + i + 1;
-            return;
-        } else if (ws) { pend++; return; }
-        // sequence character (indexer.py:75-78): counts towards seq_len whether valid or not
-        if (pend) { seq_acc += pend; run = 0; pend = 0; }     // the blanks were interior: each maps to None
-        seq_acc++;
-        uint32_t code = base_code(c);
-        if (code > 3u) { run = 0; return; }
-        fwd = (KT)(((fwd << 2) | (KT)code) & mask);           // indexer.py:149
-        rev = (KT)((rev >> 2) | ((KT)(3u - code) << top));    // indexer.py:150
-        if (run < k) run++;
-        if (run == k && rec) {                                // text before the first header is dropped (indexer.py:80-82)
-            sink.emit((uint64_t)(fwd < rev ? fwd : rev));     // indexer.py:341
-            kmer_acc++;
-        }
+    for_each_byte(lds, nb, [&](uint32_t i, uint32_t c, bool act) {
+        KT canon;
+        if (wk.step(i, c, act, canon)) sink.emit((uint64_t)canon);
     });
     sink.flush();
-    flush_rec();
-
-    // totals: wave reduce, one atomic per wave
-    for (int d = 32; d; d >>= 1) {
-        seq_tot += __shfl_down((unsigned long long)seq_tot, d, 64);
-        kmer_tot += __shfl_down((unsigned long long)kmer_tot, d, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (seq_tot) atomicAdd((unsigned long long *)&carry->total_bp, (unsigned long long)seq_tot);
-        if (kmer_tot) atomicAdd((unsigned long long *)&carry->num_kmers, (unsigned long long)kmer_tot);
-    }
+    wk.flush_rec_wave();
+    wk.finish();
+    recacc_finish(racc, recs, recs_cap, carry);
 }
 
 // ------------------------------------------------------------------ clamp + histogram ----------

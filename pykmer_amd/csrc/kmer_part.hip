@@ -23,6 +23,7 @@
 // only when a bucket's counters leave LDS (indexer.py:239,262), and K6 folds the slice already in
 // HBM back in, so several feeds accumulate exactly like the reference's flushes.
 #include "fasta_fsm.h"
+#include "kmer_walk.h"
 #include "pk_kernels.h"
 
 namespace pk {
@@ -113,41 +114,25 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
     const uint32_t k = pl.k, km1 = k - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t d = threadIdx.x; d < pl.B1; d += WG) hist1[d] = 0;
-    const KT mask = (KT)((k >= sizeof(KT) * 4) ? ~(KT)0 : (((KT)1 << (2 * k)) - 1));
-    const uint32_t top = 2 * km1;
     const uint32_t shift1 = pl.addr_bits - pl.b1;
-    uint64_t seq_tot = 0, kmer_tot = 0;
+    __shared__ RecAcc racc;
+    recacc_init(racc);
+    Walker<KT> wk;
+    wk.setup(k, recs, recs_cap, &racc);
     const uint32_t c_lo = blockIdx.x * pl.G, c_hi = min(c_lo + pl.G, pl.n_chunks);
     __syncthreads();
     for (uint32_t c = c_lo; c < c_hi; c++) {
         const uint64_t base = (uint64_t)c * CHUNK;
+        recacc_retarget(racc, chunk_l2_state[c].rec, recs, recs_cap);    // published by the barrier below
         stage_chunk(fasta, base, n_bytes, lds);
         __syncthreads();
         const uint32_t nb = piece_len(base, n_bytes);
         L1 tot1;
         L1 st1 = wg_excl_scan_l1(piece_l1(lds, nb), chunk_l1_state[c], sh1, &tot1);
-        uint32_t ls = l1_kind(st1);
+        const uint32_t ls_in = l1_kind(st1);
         L2 tot2;
-        L2 st2 = wg_excl_scan_l2(piece_l2(lds, nb, ls, km1), chunk_l2_state[c], sh2, &tot2, km1);
-
-        uint64_t pend = st2.p_tail;
-        uint32_t run = l2_len(st2), rec = st2.rec;
-        KT fwd = (KT)st2.bits, rev = 0;
-        for (uint32_t i = 0; i < run; i++) {
-            uint32_t b = (st2.bits >> (2 * (run - 1 - i))) & 3u;
-            rev = (rev >> 2) | ((KT)(3u - b) << top);
-        }
-        uint64_t seq_acc = 0, kmer_acc = 0, name_end = 0;
-        const uint64_t pos0 = stream_off + base + (uint64_t)threadIdx.x * PIECE;
-        auto flush_rec = [&]() {
-            if (rec && rec <= recs_cap) {
-                if (seq_acc) atomicAdd((unsigned long long *)&recs[rec - 1].seq_len, (unsigned long long)seq_acc);
-                if (kmer_acc) atomicAdd((unsigned long long *)&recs[rec - 1].n_valid, (unsigned long long)kmer_acc);
-                if (name_end) atomicMax((unsigned long long *)&recs[rec - 1].name_end, (unsigned long long)name_end);
-            }
-            if (rec) { seq_tot += seq_acc; kmer_tot += kmer_acc; }
-            seq_acc = 0; kmer_acc = 0; name_end = 0;
-        };
+        L2 st2 = wg_excl_scan_l2(piece_l2(lds, nb, ls_in, km1), chunk_l2_state[c], sh2, &tot2, km1);
+        wk.begin(ls_in, st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
 
         REC0 *region = flat + ((uint64_t)c * (WG / 64) + wave) * SUB;
         uint32_t wcount = 0;                               // wave-uniform
@@ -163,67 +148,21 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
             }
             wcount += __popcll(m);
         };
-        const uint8_t *mine = lds + threadIdx.x * LDS_STRIDE;
-#pragma unroll 1
-        for (int q = 0; q < PIECE / 16; q++) {
-            uint4 v = *reinterpret_cast<const uint4 *>(mine + q * 16);
-            uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const uint32_t i = q * 16 + j;
-                const uint32_t ch = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                bool has = false;
-                KT canon = 0;
-                if (i < nb) {
-                    if (is_term(ch)) { pend = 0; ls = LS_START; }
-                    else {
-                        bool ws = is_ws(ch), seqchar = false;
-                        if (ls == LS_START) {
-                            if (!ws) {
-                                if (ch == '>') {
-                                    flush_rec();
-                                    rec++;
-                                    if (rec <= recs_cap) recs[rec - 1].name_off = pos0 + i + 1;
-                                    name_end = pos0 + i + 1;
-                                    run = 0;
-                                    ls = LS_HEADER;
-                                } else { ls = LS_SEQ; seqchar = true; }
-                            }
-                        } else if (ls == LS_HEADER) {
-                            if (!ws) name_end = pos0 + i + 1;
-                        } else if (ws) pend++;
-                        else seqchar = true;
-                        if (seqchar) {
-                            if (pend) { seq_acc += pend; run = 0; pend = 0; }
-                            seq_acc++;
-                            uint32_t code = base_code(ch);
-                            if (code > 3u) run = 0;
-                            else {
-                                fwd = (KT)(((fwd << 2) | (KT)code) & mask);
-                                rev = (KT)((rev >> 2) | ((KT)(3u - code) << top));
-                                if (run < k) run++;
-                                if (run == k && rec) { has = true; canon = fwd < rev ? fwd : rev; kmer_acc++; }
-                            }
-                        }
-                    }
-                }
-                // lane-local run merging: only k-mers seen once in the last four distinct ones are emitted
-                bool emit = false;
-                KT ea = 0;
-                if (has) {
-                    if (c0 && canon == a0) c0++;
-                    else if (c1 && canon == a1) c1++;
-                    else if (c2 && canon == a2) c2++;
-                    else if (c3 && canon == a3) c3++;
-                    else {
-                        if (c3 == 1u) { emit = true; ea = a3; }
-                        else if (c3 >= 2u) hot_insert(hot, (uint64_t)a3, c3, side, side_n, side_cap);
-                        a3 = a2; c3 = c2; a2 = a1; c2 = c1; a1 = a0; c1 = c0; a0 = canon; c0 = 1u;
-                    }
-                }
-                wave_emit(emit, ea);
-            }
-        }
+        for_each_byte(lds, nb, [&](uint32_t i, uint32_t ch, bool act) {
+            KT canon;
+            const bool has = wk.step(i, ch, act, canon);
+            // lane-local run merging: only k-mers seen once among the last four distinct ones are emitted
+            const bool m0 = has && c0 && canon == a0, m1 = has && c1 && canon == a1;
+            const bool m2 = has && c2 && canon == a2, m3 = has && c3 && canon == a3;
+            const bool miss = has && !(m0 || m1 || m2 || m3);
+            c0 += m0 ? 1u : 0u; c1 += (!m0 && m1) ? 1u : 0u;
+            c2 += (!m0 && !m1 && m2) ? 1u : 0u; c3 += (!m0 && !m1 && !m2 && m3) ? 1u : 0u;
+            const bool emit = miss && c3 == 1u;
+            const KT ea = a3;
+            if (miss && c3 >= 2u) hot_insert(hot, (uint64_t)a3, c3, side, side_n, side_cap);
+            if (miss) { a3 = a2; c3 = c2; a2 = a1; c2 = c1; a1 = a0; c1 = c0; a0 = canon; c0 = 1u; }
+            wave_emit(emit, ea);
+        });
         // drain the lane caches (oldest first)
         {
             KT fa[4] = {a3, a2, a1, a0};
@@ -234,20 +173,14 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
                 wave_emit(fc[e] == 1u, fa[e]);
             }
         }
-        flush_rec();
+        wk.flush_rec_wave();
         if (lane == 0) cnt[c * (WG / 64) + wave] = wcount;
         __syncthreads();                                   // pieces consumed; LDS may be restaged
         if (hot.used >= HOT_SLOTS / 2) hot_flush(hot, side, side_n, side_cap);   // uniform: read after the barrier
     }
     hot_flush(hot, side, side_n, side_cap);
-    for (int d = 32; d; d >>= 1) {
-        seq_tot += __shfl_down((unsigned long long)seq_tot, d, 64);
-        kmer_tot += __shfl_down((unsigned long long)kmer_tot, d, 64);
-    }
-    if (lane == 0) {
-        if (seq_tot) atomicAdd((unsigned long long *)&carry->total_bp, (unsigned long long)seq_tot);
-        if (kmer_tot) atomicAdd((unsigned long long *)&carry->num_kmers, (unsigned long long)kmer_tot);
-    }
+    wk.finish();
+    recacc_finish(racc, recs, recs_cap, carry);
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < pl.B1; d += WG) hist1_rows[(uint64_t)blockIdx.x * pl.B1 + d] = hist1[d];
 }
