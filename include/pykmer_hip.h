@@ -42,6 +42,13 @@ int pk_version(void);
 int pk_last_error(char *buf, size_t n);
 int pk_device_count(void);
 
+/* ---- plain device buffers, so a host in any language can stage tables in HBM one at a time (a k=17
+ * merge holds N x 16 GiB on the device, never on the host) and hand slices to pk_gram_device_partial. */
+int pk_dev_alloc(void **dev_out, uint64_t n_bytes, int device);
+int pk_dev_free(void *dev, int device);
+int pk_dev_upload(void *dev_dst, const void *host_src, uint64_t n_bytes, int device);
+int pk_dev_download(void *host_dst, const void *dev_src, uint64_t n_bytes, int device);
+
 /* ---- indexer: replaces gen_kmers + canonical min + process_kmers (indexer.py:130-160, 341, 162-297)
  * and the parser that feeds them (indexer.py:45-99).  k must be odd, 1 <= k <= 17 (tools.py:165-167).
  *

@@ -19,6 +19,10 @@ _SIGNATURES = {
     "pk_version": (ctypes.c_int, []),
     "pk_last_error": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
     "pk_device_count": (ctypes.c_int, []),
+    "pk_dev_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint64, ctypes.c_int]),
+    "pk_dev_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "pk_dev_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]),
+    "pk_dev_download": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]),
     "pk_count_fasta": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, _u64p, _u64p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, _u64p, ctypes.c_int]),
     "pk_indexer_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
@@ -111,6 +115,34 @@ def device_count() -> int:
 
 def _hist_out():
     return np.zeros(256, dtype=np.uint64)
+
+
+class DeviceBuffer:
+    """n bytes of HBM on one device (pk_dev_*)."""
+
+    def __init__(self, n_bytes: int, device: int = 0):
+        self.n, self.device = int(n_bytes), device
+        p = ctypes.c_void_p()
+        _check(load().pk_dev_alloc(ctypes.byref(p), self.n, device))
+        self.ptr = p.value
+
+    def upload(self, data, offset: int = 0):
+        buf = _as_u8(data)
+        assert offset + buf.size <= self.n
+        _check(load().pk_dev_upload(ctypes.c_void_p(self.ptr + offset), buf.ctypes.data, buf.size, self.device))
+
+    def download(self, n_bytes: int = None, offset: int = 0) -> np.ndarray:
+        n = self.n - offset if n_bytes is None else n_bytes
+        out = np.empty(n, dtype=np.uint8)
+        _check(load().pk_dev_download(out.ctypes.data, ctypes.c_void_p(self.ptr + offset), n, self.device))
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            load().pk_dev_free(ctypes.c_void_p(self.ptr), self.device)
+            self.ptr = None
+
+    __del__ = free
 
 
 class Indexer:

@@ -54,6 +54,32 @@ static int check_k(int k) {
     return PK_OK;
 }
 
+// ================================================================== device buffers =============
+extern "C" int pk_dev_alloc(void **dev_out, uint64_t n_bytes, int device) {
+    if (!dev_out) return fail(PK_ERR_ARG, "null output pointer");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMalloc(dev_out, n_bytes + 64));            // slack: kernels read whole 16/32-byte words
+    return PK_OK;
+}
+extern "C" int pk_dev_free(void *dev, int device) {
+    if (!dev) return PK_OK;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipFree(dev));
+    return PK_OK;
+}
+extern "C" int pk_dev_upload(void *dev_dst, const void *host_src, uint64_t n_bytes, int device) {
+    if (n_bytes && (!dev_dst || !host_src)) return fail(PK_ERR_ARG, "null pointer");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpy(dev_dst, host_src, n_bytes, hipMemcpyHostToDevice));
+    return PK_OK;
+}
+extern "C" int pk_dev_download(void *host_dst, const void *dev_src, uint64_t n_bytes, int device) {
+    if (n_bytes && (!host_dst || !dev_src)) return fail(PK_ERR_ARG, "null pointer");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpy(host_dst, dev_src, n_bytes, hipMemcpyDeviceToHost));
+    return PK_OK;
+}
+
 // ================================================================== indexer ====================
 struct pk_indexer {
     int k = 0, device = 0;

@@ -1,0 +1,197 @@
+"""Merger host side: N `.kin[.bgz]` tables in, `<project>.<min>-<max>.kma` + `.kma.json` out.
+
+Same CLI, checks and outputs as the reference's merger.py (argparse :51-59, merge :80-210, main
+:213-239).  The reference runs Header.calculate_distance once per pair in a process pool
+(merger.py:137-153), reading both tables each time; here every table is staged in HBM once and ONE
+kernel pass (pk_gram_device_partial) yields all N(N+1)/2 tallies.  With several GPUs the k-mer
+address range is split across them; with torch.distributed initialised (one process per GPU) each
+rank scans its slice and the N x N partials are summed by one all-reduce (RCCL over xGMI).
+"""
+import argparse
+import json
+import os
+import pathlib
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from json import JSONEncoder
+from pathlib import Path
+from typing import List, Tuple
+
+import numpy as np
+
+from . import _lib
+from .header import Header
+
+EXTS = ("." + Header.IND_EXT, "." + Header.IND_EXT + "." + Header.COMP_EXT, ".kma", ".kma." + Header.COMP_EXT)
+
+DEFAULT_MIN_COUNT = Header.DEFAULT_MIN_COUNT
+DEFAULT_MAX_COUNT = Header.DEFAULT_MAX_COUNT
+DEFAULT_BUFFER_SIZE = Header.DEFAULT_BUFFER_SIZE
+DEFAULT_BLOCK_SIZE = Header.DEFAULT_BLOCK_SIZE
+DEFAULT_THREADS = 4
+
+
+class _Encoder(JSONEncoder):
+    """merger.py:23-30 patches JSONEncoder globally so Path objects serialise as strings; same effect, scoped."""
+
+    def default(self, obj):
+        if isinstance(obj, pathlib.PurePath):
+            return str(obj)
+        if hasattr(obj.__class__, "to_dict"):
+            return obj.to_dict()
+        return super().default(obj)
+
+
+def build_parser() -> argparse.ArgumentParser:
+    parser = argparse.ArgumentParser(description="Merge kmer databases.")
+    parser.add_argument("Project_Name", metavar="P", type=str, help="Project name")
+    parser.add_argument("Kmer_1", metavar="K", type=Path, nargs=1, help="List of kin files")
+    parser.add_argument("Kmer_N", metavar="K", type=Path, nargs="+", help="List of kin files")
+    parser.add_argument("--min-count", type=int, default=DEFAULT_MIN_COUNT, nargs="?", help=f"Minimum Kmer Count [{DEFAULT_MIN_COUNT}]")
+    parser.add_argument("--max-count", type=int, default=DEFAULT_MAX_COUNT, nargs="?", help=f"Maximum Kmer Count [{DEFAULT_MAX_COUNT}]")
+    parser.add_argument("--buffer-size", type=int, default=DEFAULT_BUFFER_SIZE, nargs="?", help=f"Buffer size [{DEFAULT_BUFFER_SIZE}]")
+    parser.add_argument("--block-size", type=int, default=DEFAULT_BLOCK_SIZE, nargs="?", help=f"Block size [{DEFAULT_BLOCK_SIZE}]")
+    parser.add_argument("--threads", type=int, default=DEFAULT_THREADS, nargs="?",
+                        help=f"Host threads reading / inflating the tables [{DEFAULT_THREADS}]")
+    return parser
+
+
+def calculate_distance(k_index_file: str, l_index_file: str, min_count: int = DEFAULT_MIN_COUNT, max_count: int = DEFAULT_MAX_COUNT,
+                       buffer_size: int = DEFAULT_BUFFER_SIZE, block_size: int = DEFAULT_BLOCK_SIZE) -> Tuple[int, int, int]:
+    """merger.py:62-78: one pair, from paths."""
+    k_header = Header(str(k_index_file), index_file=str(k_index_file), buffer_size=buffer_size)
+    l_header = Header(str(l_index_file), index_file=str(l_index_file), buffer_size=buffer_size)
+    return k_header.calculate_distance(l_header, min_count=min_count, max_count=max_count, block_size=block_size, threading=True)
+
+
+def address_slice(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous slice of the k-mer address range owned by `rank` (multiples of 32 addresses)."""
+    per = ((n + world - 1) // world + 31) & ~31
+    lo = min(n, per * rank)
+    return lo, min(n, lo + per)
+
+
+def gpu_partial(headers: List[Header], lo: int, hi: int, min_count: int, max_count: int, device: int, threads: int) -> np.ndarray:
+    """Stage addresses [lo, hi) of every table in HBM on `device` and tally them in one kernel pass."""
+    N = len(headers)
+    bufs = [_lib.DeviceBuffer(hi - lo, device) for _ in range(N)]
+
+    def stage(i):
+        table = headers[i].read_table()                       # read / inflate on a host thread (GIL released in I/O and zlib)
+        bufs[i].upload(table[lo:hi])
+    try:
+        with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+            list(pool.map(stage, range(N)))
+        part, _ = _lib.gram_device_partial([b.ptr for b in bufs], hi - lo, min_count, max_count, device=device)
+    finally:
+        for b in bufs:
+            b.free()
+    return part
+
+
+def pair_matrix(headers: List[Header], min_count: int, max_count: int, threads: int = DEFAULT_THREADS, devices=(0,),
+                group=None, partial_fn=gpu_partial) -> np.ndarray:
+    """N x N u64: [i][i] = valid addresses of table i, [i][j] (i<j) = addresses valid in both.
+
+    Single process: the address range is split over `devices`.  With `group` (a torch.distributed
+    process group, or True for the default group) this rank scans only its own slice on devices[0]
+    and the N x N partials are summed by one all-reduce.  `partial_fn` computes one slice's tallies
+    (the GPU path above; the CPU-only distributed tests substitute the oracle)."""
+    n, N = headers[0].data_size, len(headers)
+    if group is not None:
+        import torch.distributed as dist
+        pg = None if group is True else group
+        plan = [(devices[0],) + address_slice(n, dist.get_rank(pg), dist.get_world_size(pg))]
+    else:
+        plan = [(d,) + address_slice(n, i, len(devices)) for i, d in enumerate(devices)]
+    total = np.zeros((N, N), dtype=np.uint64)
+    for dev, lo, hi in plan:
+        if hi > lo:
+            total += partial_fn(headers, lo, hi, min_count, max_count, dev, threads)
+    if group is not None:
+        import torch
+        import torch.distributed as dist
+        pg = None if group is True else group
+        t = torch.from_numpy(total.view(np.int64).copy())
+        if dist.get_backend(pg) == "nccl":
+            t = t.to(torch.device("cuda", devices[0]))
+        dist.all_reduce(t, group=pg)                           # sum of the N x N partials (RCCL over xGMI on GPUs)
+        total = t.cpu().numpy().view(np.uint64)
+    return total
+
+
+def merge(project_name: str, indexes: List[Path], min_count: int = DEFAULT_MIN_COUNT, max_count: int = DEFAULT_MAX_COUNT,
+          buffer_size: int = DEFAULT_BUFFER_SIZE, block_size: int = DEFAULT_BLOCK_SIZE, threads: int = DEFAULT_THREADS,
+          devices=(0,), group=None, partial_fn=gpu_partial):
+    """merger.py:80-210."""
+    assert min_count >= 1
+    assert max_count <= 255
+    assert buffer_size > 0
+    assert block_size > 0
+    assert len(indexes) > 0
+
+    outfile = Path(f"{project_name}.{min_count:03d}-{max_count:03d}.kma")
+    assert not Path(project_name).exists(), f"project name ({project_name}) is a file. maybe forgot to pass project name as first argument?"
+    assert not outfile.exists(), f"project output file ({outfile}) already exists. not overwriting."
+
+    indexes = [Path(p) for p in indexes]
+    assert all(i.exists() for i in indexes)
+
+    data, headers, kmer_len = [], [], None
+    for pos, kin in enumerate(indexes):
+        print(f"verifying {kin}")
+        kins = str(kin)
+        assert kins.endswith(EXTS), f"all files must be .{Header.IND_EXT}[.bgz]: {kin}"
+        desc = kins[:-(len(Header.COMP_EXT) + 1)] if kins.endswith("." + Header.COMP_EXT) else kin
+        desc = Path(f"{desc}.{Header.DESC_EXT}")
+        assert desc.exists(), f"all .{Header.IND_EXT}[.{Header.COMP_EXT}] files must have a associated .{Header.IND_EXT}.{Header.DESC_EXT}: {desc}"
+        header = Header(kins, index_file=kins, buffer_size=buffer_size, device=devices[0])
+        if kmer_len is None:
+            kmer_len = header.kmer_len
+        assert header.kmer_len == kmer_len, f"kmer_length differs. expected {kmer_len}, got {header.kmer_len}"
+        headers.append(header)
+        data.append({"pos": pos, "index_file": kin, "description_file": desc, "header": header})
+    print()
+
+    pair = pair_matrix(headers, min_count, max_count, threads=threads, devices=devices, group=group, partial_fn=partial_fn)
+    # (N,N,3): [k][l] = (total_k, total_l, shared) (merger.py:175-176); the diagonal, which the reference
+    # never assigns in its uninitialised array (merger.py:136), is zero here
+    matrix = _lib.gram_expand(pair)
+    for k in range(len(data) - 1):
+        for l in range(k + 1, len(data)):
+            print(f"   matrix Total #{k:3d} {int(matrix[k, l, 0]):15,d} Total #{l:3d} {int(matrix[k, l, 1]):15,d} Shared {int(matrix[k, l, 2]):15,d}")
+
+    for v in data:
+        v["header"] = v["header"].to_dict(lean=True)          # merger.py:187-188
+    output = {"project_name": project_name, "min_count": min_count, "max_count": max_count, "data": data}
+
+    is_writer = True
+    if group is not None:
+        import torch.distributed as dist
+        is_writer = dist.get_rank(None if group is True else group) == 0
+    if is_writer:
+        outfile_json = Path(f"{outfile}.json")
+        outfile_json_tmp = Path(f"{outfile_json}.tmp")
+        print(f"saving {outfile_json}")
+        with outfile_json_tmp.open(mode="wt") as fhd:
+            json.dump(output, fhd, sort_keys=True, indent=1, cls=_Encoder)
+        outfile_json_tmp.rename(outfile_json)
+        print(f"saving {outfile}")
+        outfile_tmp = Path(f"{outfile}.tmp")
+        with outfile_tmp.open(mode="wb") as fhd:
+            np.savez_compressed(fhd, matrix=matrix)            # merger.py:207: key `matrix`
+        outfile_tmp.rename(outfile)
+    return data, matrix
+
+
+def main(argv: List[str] = None) -> None:
+    """merger.py:213-239."""
+    args = build_parser().parse_args(argv)
+    indexes: List[Path] = args.Kmer_1 + args.Kmer_N
+    if len(indexes) <= 1:
+        print("needs at least 2 files")
+        sys.exit(1)
+    indexes.sort()                                             # matrix order = sorted path order (merger.py:228)
+    devices = tuple(int(d) for d in os.environ.get("PK_DEVICES", "0").split(",") if d != "")
+    merge(args.Project_Name, indexes, min_count=args.min_count, max_count=args.max_count, buffer_size=args.buffer_size,
+          block_size=args.block_size, threads=args.threads, devices=devices or (0,))

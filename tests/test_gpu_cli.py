@@ -1,0 +1,79 @@
+"""GPU end to end: the two drop-in CLIs, files on disk, against what the reference wrote (goldens)."""
+import gzip
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import inputs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv, cwd):
+    r = subprocess.run([sys.executable] + list(argv), cwd=cwd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("name", ["G2_c1_k7", "G3_edge_k9", "G3_edge_gz_k7", "G3_edge_k15"])
+def test_indexer_cli_writes_reference_files(gpu, tmp_path, manifest, small_tables, name):
+    case = manifest["indexer"][name]
+    fa = tmp_path / case["input_file"]
+    data = inputs.make_input(case["input"])
+    fa.write_bytes(data)
+    _run(os.path.join(ROOT, "indexer.py"), str(fa), "sample", str(case["k"]), cwd=str(tmp_path))
+    kin = f"{fa}.{case['k']:02d}.kin"
+    assert os.path.getsize(kin) == 4 ** case["k"] and not os.path.exists(kin + ".tmp")
+    with open(kin + ".json") as fh:
+        meta = json.load(fh)
+    assert sorted(meta.keys()) == case["reference_keys"]
+    skip = {"input_file_cheksum", "input_file_size"} if name == "G3_edge_gz_k7" else set()   # gzip bytes depend on the zlib build
+    for f, v in case["expect"].items():
+        if f not in skip:
+            assert meta[f] == v, f
+    if name in small_tables:
+        assert np.array_equal(np.fromfile(kin, dtype=np.uint8), small_tables[name])
+    assert meta["project_name"] == str(fa) and meta["input_file_path"] == str(fa)
+
+
+def test_indexer_cli_readme_form_and_refusal(gpu, tmp_path):
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(inputs.edge_fasta())
+    _run(os.path.join(ROOT, "indexer.py"), str(fa), "7", cwd=str(tmp_path))          # README.md:22: indexer.py <file> <K>
+    assert os.path.exists(f"{fa}.07.kin.json")
+    empty = tmp_path / "n.fa"
+    empty.write_bytes(b">all_n\nNNNNNNNNNNNNNNNN\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "indexer.py"), str(empty), "s", "7"], capture_output=True, text=True)
+    assert r.returncode != 0 and "AssertionError" in r.stderr                        # tools.py:367: no k-mers -> assert
+
+
+def test_merger_cli_matches_reference_matrix(gpu, tmp_path, manifest):
+    case = manifest["merger"]["G7_k7_n13_max3"]
+    kins = []
+    for i, spec in enumerate(case["inputs"]):
+        fa = tmp_path / f"s{i:02d}.fa"
+        fa.write_bytes(inputs.make_input(spec))
+        _run(os.path.join(ROOT, "indexer.py"), str(fa), f"s{i}", "7", cwd=str(tmp_path))
+        kins.append(f"{fa}.07.kin")
+    with open(kins[4], "rb") as fh, gzip.open(kins[4] + ".bgz", "wb") as out:        # Header.index_file then prefers the .bgz
+        out.write(fh.read())
+    proj = str(tmp_path / "proj")
+    _run(os.path.join(ROOT, "merger.py"), proj, *reversed(kins), "--max-count", "3", "--threads", "3", cwd=str(tmp_path))
+    m = np.load(proj + ".001-003.kma")["matrix"]
+    assert m.dtype == np.uint64 and np.array_equal(m, np.array(case["matrix"], dtype=np.uint64))
+    with open(proj + ".001-003.kma.json") as fh:
+        meta = json.load(fh)
+    assert sorted(meta.keys()) == case["kma_json_keys"]
+    assert sorted(meta["data"][0]["header"].keys()) == case["kma_json_header_keys"]
+    assert [os.path.basename(d["index_file"]) for d in meta["data"]] == case["order"]  # sorted, whatever the argv order
+    # the pair API the reference's pool workers call (merger.py:62-78)
+    from pykmer_amd import merger
+    assert merger.calculate_distance(kins[0], kins[1], max_count=3) == tuple(int(x) for x in m[0, 1])
+    # read-back validator (indexer.py:416-444, working here)
+    from pykmer_amd import indexer
+    indexer.read_fasta_index("p", index_file=kins[2])
