@@ -97,15 +97,20 @@ def main():
     assert fin["total_bp"] == total_bp, (fin["total_bp"], total_bp)
     value = bp_job * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel (k_count): algorithmic bytes = FASTA read once + table written once
-    alg_bytes = n_bytes + 4 ** k                                   # F + 4^k  (2.36 B/bp on C2 at k=15)
+    # ---- roofline of the dominant kernel (the k-mer walk: k_walk_flat, or k_count in direct mode).
+    # Algorithmic bytes = FASTA read once + table written once (F + 4^k, 2.36 B/bp on C2 at k=15);
+    # duration = that kernel's launches timed with HIP events on the indexer's stream (pk_indexer_timings).
+    alg_bytes = n_bytes + 4 ** k
     count_avg = count_s / args.steps
     achieved = alg_bytes / count_avg / 1e9
-    traffic = None
+    dominant = "k_count" if t["direct"] else "k_walk_flat"
+    traffic = pipeline_traffic = None
     tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tp):
+    if os.path.exists(tp) and k == 15 and args.bp == 800_000_000:  # PMC bytes were collected on exactly this workload
         with open(tp) as fh:
-            traffic = json.load(fh).get("k_count", {}).get("bytes_per_launch")
+            tj = json.load(fh)
+        traffic = tj.get(dominant, {}).get("bytes_per_launch")
+        pipeline_traffic = tj.get("_pipeline_bytes_per_step")
     out = {
         "metric": "bp/s k-mer counted (k=15, 1 GPU)" if k == 15 else f"bp/s k-mer counted (k={k})",
         "value": value, "unit": "bp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -114,9 +119,11 @@ def main():
         "config": {"workload": f"k={k} canonical k-mer count of one {total_bp / 1e6:.0f} Mbp synthetic genome per GPU "
                                f"(SURVEY 8d C2, seed 2+rank), 4^{k} table resident in HBM",
                    "fasta_bytes": n_bytes, "num_kmers": fin["num_kmers"], "parallelism": f"{world} independent genome(s)"},
-        "roofline": {"bound": "hbm", "kernel": "k_count", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": count_avg * 1e3},
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": count_avg * 1e3,
+                     "pipeline_traffic_bytes_per_step": pipeline_traffic,
+                     "pipeline_hbm_GBps": (pipeline_traffic / (elapsed / args.steps) / 1e9) if pipeline_traffic else None},
         "stage_ms": {"zero_table": zero_s / args.steps * 1e3, "structure_scans": scan_s / args.steps * 1e3,
                      "walk_kernel": count_avg * 1e3, "partition_passes": part_s / args.steps * 1e3,
                      "bucket_count": bucket_s / args.steps * 1e3, "histogram": final_s / args.steps * 1e3,

@@ -205,17 +205,48 @@ __device__ __forceinline__ void for_each_byte(const uint8_t *lds, uint32_t nb, F
     }
 }
 
-// L1 summary of the lane's piece.
-__device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb) {
+// L1 summary of the lane's piece.  `dirty` comes back true if the piece holds anything besides
+// sequence characters and line terminators (a blank other than \n / \r, or a '>'): such pieces need
+// the full state machine; pieces that are not dirty and do not start inside a header line are
+// "clean" and take the short paths below and in kmer_walk.h.
+__device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb, bool &dirty) {
     uint32_t st = LS_START;
-    bool ht = false;
+    bool ht = false, d = false;
     for_each_byte(lds, nb, [&](uint32_t, uint32_t c, bool act) {
-        bool term = act && is_term(c);
-        bool opens = act && st == LS_START && !is_ws(c);
-        st = term ? (uint32_t)LS_START : opens ? (c == '>' ? (uint32_t)LS_HEADER : (uint32_t)LS_SEQ) : st;
+        const bool ws = is_ws(c), gt = c == '>';
+        const bool term = act && is_term(c);
+        const bool opens = act && st == LS_START && !ws;
+        st = term ? (uint32_t)LS_START : opens ? (gt ? (uint32_t)LS_HEADER : (uint32_t)LS_SEQ) : st;
         ht |= term;
+        d |= act && ((ws && !term) || gt);
     });
+    dirty = d;
     return nb ? l1_make(ht, st) : 0u;
+}
+__device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb) {
+    bool dirty;
+    return piece_l1(lds, nb, dirty);
+}
+
+// L2 summary of a CLEAN piece (only sequence characters and terminators, not starting in a header
+// line): no record opens, no whitespace stays pending, so only the trailing <= k-1 valid bases
+// matter -- read backwards from the end instead of walking all 64 bytes.
+__device__ __forceinline__ L2 piece_l2_clean(const uint8_t *lds, uint32_t nb, uint32_t ls_in, uint32_t km1) {
+    if (nb == 0) return l2_identity();
+    const uint8_t *mine = lds + threadIdx.x * LDS_STRIDE;
+    uint32_t flags = F_NONID | F_PRESET, len = 0, bits = 0;
+    if (ls_in == LS_SEQ && !is_term(mine[0])) flags |= F_FRONT;
+    bool open = true;                                        // still collecting
+    for (int i = (int)nb - 1; i >= 0 && open; i--) {
+        const uint32_t c = mine[i];
+        if (is_term(c)) continue;
+        const uint32_t code = base_code(c);
+        if (code > 3u || len >= km1) { flags |= F_BRK; open = false; }
+        else { bits |= code << (2u * len); len++; }
+    }
+    if (len >= km1) flags |= F_BRK;
+    L2 s; s.flags = flags | (len << 8); s.bits = bits; s.rec = 0; s.p_tail = 0;
+    return s;
 }
 
 // L2 summary of the lane's piece, given its exact incoming line state.

@@ -39,8 +39,12 @@ __global__ __launch_bounds__(WG) void k_chunk_l2(const uint8_t *__restrict__ fas
     __syncthreads();
     uint32_t nb = piece_len(base, n_bytes);
     L1 tot1;
-    L1 st1 = wg_excl_scan_l1(piece_l1(lds, nb), chunk_l1_state[blockIdx.x], sh1, &tot1);
-    L2 mine = piece_l2(lds, nb, l1_kind(st1), km1);
+    bool dirty;
+    L1 my1 = piece_l1(lds, nb, dirty);
+    L1 st1 = wg_excl_scan_l1(my1, chunk_l1_state[blockIdx.x], sh1, &tot1);
+    const uint32_t ls_in = l1_kind(st1);
+    const bool wave_clean = __all(!dirty && ls_in != LS_HEADER);          // wave-uniform choice of path
+    L2 mine = wave_clean ? piece_l2_clean(lds, nb, ls_in, km1) : piece_l2(lds, nb, ls_in, km1);
     L2 total;
     wg_excl_scan_l2(mine, l2_identity(), sh2, &total, km1);
     if (threadIdx.x == 0) chunk_l2[blockIdx.x] = total;
@@ -120,10 +124,14 @@ __global__ __launch_bounds__(WG) void k_count(const uint8_t *__restrict__ fasta,
     __syncthreads();
     uint32_t nb = piece_len(base, n_bytes);
     L1 tot1;
-    L1 st1 = wg_excl_scan_l1(piece_l1(lds, nb), chunk_l1_state[blockIdx.x], sh1, &tot1);
+    bool dirty;
+    L1 my1 = piece_l1(lds, nb, dirty);
+    L1 st1 = wg_excl_scan_l1(my1, chunk_l1_state[blockIdx.x], sh1, &tot1);
     uint32_t ls = l1_kind(st1);
+    const bool l2_clean = __all(!dirty && ls != LS_HEADER);
     L2 tot2;
-    L2 st2 = wg_excl_scan_l2(piece_l2(lds, nb, ls, km1), chunk_l2_state[blockIdx.x], sh2, &tot2, km1);
+    L2 st2 = wg_excl_scan_l2(l2_clean ? piece_l2_clean(lds, nb, ls, km1) : piece_l2(lds, nb, ls, km1),
+                             chunk_l2_state[blockIdx.x], sh2, &tot2, km1);
 
     // exact parser state at this lane's first byte
     __shared__ RecAcc racc;
@@ -136,10 +144,17 @@ __global__ __launch_bounds__(WG) void k_count(const uint8_t *__restrict__ fasta,
     wk.begin(ls, st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
     DirectSink sink;
     sink.init(table32);
-    for_each_byte(lds, nb, [&](uint32_t i, uint32_t c, bool act) {
-        KT canon;
-        if (wk.step(i, c, act, canon)) sink.emit((uint64_t)canon);
-    });
+    if (__all(!dirty && ls != LS_HEADER && st2.p_tail == 0)) {
+        for_each_byte(lds, nb, [&](uint32_t, uint32_t c, bool act) {
+            KT canon;
+            if (wk.step_clean(c, act, canon)) sink.emit((uint64_t)canon);
+        });
+    } else {
+        for_each_byte(lds, nb, [&](uint32_t i, uint32_t c, bool act) {
+            KT canon;
+            if (wk.step(i, c, act, canon)) sink.emit((uint64_t)canon);
+        });
+    }
     sink.flush();
     wk.flush_rec_wave();
     wk.finish();

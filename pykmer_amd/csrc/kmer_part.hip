@@ -128,10 +128,15 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
         __syncthreads();
         const uint32_t nb = piece_len(base, n_bytes);
         L1 tot1;
-        L1 st1 = wg_excl_scan_l1(piece_l1(lds, nb), chunk_l1_state[c], sh1, &tot1);
+        bool dirty;
+        L1 my1 = piece_l1(lds, nb, dirty);
+        L1 st1 = wg_excl_scan_l1(my1, chunk_l1_state[c], sh1, &tot1);
         const uint32_t ls_in = l1_kind(st1);
+        const bool l2_clean = __all(!dirty && ls_in != LS_HEADER);        // wave-uniform
         L2 tot2;
-        L2 st2 = wg_excl_scan_l2(piece_l2(lds, nb, ls_in, km1), chunk_l2_state[c], sh2, &tot2, km1);
+        L2 st2 = wg_excl_scan_l2(l2_clean ? piece_l2_clean(lds, nb, ls_in, km1) : piece_l2(lds, nb, ls_in, km1),
+                                 chunk_l2_state[c], sh2, &tot2, km1);
+        const bool walk_clean = __all(!dirty && ls_in != LS_HEADER && st2.p_tail == 0);
         wk.begin(ls_in, st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
 
         REC0 *region = flat + ((uint64_t)c * (WG / 64) + wave) * SUB;
@@ -148,9 +153,7 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
             }
             wcount += __popcll(m);
         };
-        for_each_byte(lds, nb, [&](uint32_t i, uint32_t ch, bool act) {
-            KT canon;
-            const bool has = wk.step(i, ch, act, canon);
+        auto route = [&](bool has, KT canon) {
             // lane-local run merging: only k-mers seen once among the last four distinct ones are emitted
             const bool m0 = has && c0 && canon == a0, m1 = has && c1 && canon == a1;
             const bool m2 = has && c2 && canon == a2, m3 = has && c3 && canon == a3;
@@ -162,7 +165,20 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
             if (miss && c3 >= 2u) hot_insert(hot, (uint64_t)a3, c3, side, side_n, side_cap);
             if (miss) { a3 = a2; c3 = c2; a2 = a1; c2 = c1; a1 = a0; c1 = c0; a0 = canon; c0 = 1u; }
             wave_emit(emit, ea);
-        });
+        };
+        if (walk_clean) {                                    // the common case: plain sequence lines
+            for_each_byte(lds, nb, [&](uint32_t, uint32_t ch, bool act) {
+                KT canon;
+                const bool has = wk.step_clean(ch, act, canon);
+                route(has, canon);
+            });
+        } else {
+            for_each_byte(lds, nb, [&](uint32_t i, uint32_t ch, bool act) {
+                KT canon;
+                const bool has = wk.step(i, ch, act, canon);
+                route(has, canon);
+            });
+        }
         // drain the lane caches (oldest first)
         {
             KT fa[4] = {a3, a2, a1, a0};
@@ -342,8 +358,16 @@ __global__ __launch_bounds__(WG) void k_count2(const uint32_t *__restrict__ in, 
     uint32_t b, lo, hi;
     const bool live = wg2_range(wg2_start, bucket_base, pl, b, lo, hi);
     const uint32_t shift = pl.fb_bits;
-    if (live)
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += WG) atomicAdd(&h[(in[i] >> shift) & (pl.B2 - 1u)], 1u);
+    if (live) {
+        const uint32_t mask = pl.B2 - 1u;
+        for (uint32_t i = (lo & ~3u) + threadIdx.x * 4u; i < hi; i += WG * 4u) {      // 16 B per lane; edges masked
+            const uint4 v = *reinterpret_cast<const uint4 *>(in + i);
+            const uint32_t r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (i + q >= lo && i + q < hi) atomicAdd(&h[(r[q] >> shift) & mask], 1u);
+        }
+    }
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < pl.B2; d += WG) hist_rows[(uint64_t)blockIdx.x * pl.B2 + d] = live ? h[d] : 0u;
 }

@@ -110,6 +110,24 @@ struct Walker {
         if (seq_acc | kmer_acc | name_end) flush_rec();
     }
 
+    // One byte of a CLEAN piece (sequence characters and line terminators only, no pending blanks,
+    // not inside a header): the line/record machinery drops out.
+    __device__ __forceinline__ bool step_clean(uint32_t c, bool act, KT &canon) {
+        const bool seqchar = act && !is_term(c);
+        seq_acc += seqchar ? 1ull : 0ull;
+        const uint32_t code = base_code(c);
+        const bool valid = seqchar && code < 4u;
+        const KT nf = (KT)(((fwd << 2) | (KT)(code & 3u)) & mask);
+        const KT nr = (KT)((rev >> 2) | ((KT)(3u - (code & 3u)) << top));
+        fwd = valid ? nf : fwd;
+        rev = valid ? nr : rev;
+        run = valid ? (run < k ? run + 1 : run) : (seqchar ? 0u : run);
+        const bool has = valid && run == k && rec != 0;
+        kmer_acc += has ? 1ull : 0ull;
+        canon = fwd < rev ? fwd : rev;
+        return has;
+    }
+
     // One byte.  Returns true when a valid window ends here; canon = min(fwd, rev) (indexer.py:341).
     __device__ __forceinline__ bool step(uint32_t i, uint32_t c, bool act, KT &canon) {
         const bool term = is_term(c), ws = is_ws(c), gt = c == '>';
