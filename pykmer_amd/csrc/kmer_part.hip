@@ -22,6 +22,7 @@
 // record order (hence the result) is deterministic.  Saturation is exact: min(255, .) is applied
 // only when a bucket's counters leave LDS (indexer.py:239,262), and K6 folds the slice already in
 // HBM back in, so several feeds accumulate exactly like the reference's flushes.
+#include <cstdlib>
 #include "fasta_fsm.h"
 #include "kmer_walk.h"
 #include "pk_kernels.h"
@@ -144,16 +145,18 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
         KT a0 = 0, a1 = 0, a2 = 0, a3 = 0;                 // last four distinct canonical k-mers of this lane
         uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;           // ... and how often each was seen
         // wave-uniform call: ballot-compact this step's records into the wave's region (coalesced store)
+        const uint32_t dbg = pl.dbg;
         auto wave_emit = [&](bool e, KT a) {
             unsigned long long m = __ballot(e);
             if (e) {
                 uint32_t p = wcount + __popcll(m & ((1ull << lane) - 1ull));
-                region[p] = (REC0)a;
-                atomicAdd(&hist1[(uint32_t)((uint64_t)a >> shift1)], 1u);
+                if (!(dbg & 4u)) region[p] = (REC0)a;
+                if (!(dbg & 2u)) atomicAdd(&hist1[(uint32_t)((uint64_t)a >> shift1)], 1u);
             }
             wcount += __popcll(m);
         };
         auto route = [&](bool has, KT canon) {
+            if (dbg & 1u) { wave_emit(has, canon); return; }
             // lane-local run merging: only k-mers seen once among the last four distinct ones are emitted
             const bool m0 = has && c0 && canon == a0, m1 = has && c1 && canon == a1;
             const bool m2 = has && c2 && canon == a2, m3 = has && c3 && canon == a3;
@@ -166,7 +169,8 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
             if (miss) { a3 = a2; c3 = c2; a2 = a1; c2 = c1; a1 = a0; c1 = c0; a0 = canon; c0 = 1u; }
             wave_emit(emit, ea);
         };
-        if (walk_clean) {                                    // the common case: plain sequence lines
+        if (dbg & 8u) {
+        } else if (walk_clean) {                             // the common case: plain sequence lines
             for_each_byte(lds, nb, [&](uint32_t, uint32_t ch, bool act) {
                 KT canon;
                 const bool has = wk.step_clean(ch, act, canon);
@@ -569,6 +573,8 @@ PartPlan make_part_plan(uint32_t k, uint64_t n_bytes) {
     uint64_t r2 = (n_bytes + 1023) / 1024;
     pl.R2 = r2 < (uint64_t)TILE ? (uint64_t)TILE : ((r2 + TILE - 1) / TILE) * TILE;
     pl.n_wg2_max = (uint32_t)(n_bytes / pl.R2) + pl.B1 + 1;
+    const char *dbg = getenv("PK_DEBUG_WALK");
+    pl.dbg = dbg ? (uint32_t)atoi(dbg) : 0u;
     return pl;
 }
 
@@ -615,6 +621,10 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
                            (uint64_t *)flat, cnt, hist1, recs, recs_cap, carry, side, side_n, lay.side_cap);
     }
     if (ev_walk_end) hipEventRecord(ev_walk_end, s);
+    if (pl.dbg) {                                            // ablation run: time the walk kernel only, results are garbage
+        if (ev_part_end) hipEventRecord(ev_part_end, s);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     hipLaunchKernelGGL(k_rows1_scan, dim3(1), dim3(512), 0, s, hist1, rowoff1, pl, bucket_base, wg2_start, final_start);
     if (pl.k <= 15)
         hipLaunchKernelGGL(k_scatter1<uint32_t>, dim3(pl.n_wg0), dim3(SC_T), sizeof(ScatterLds), s, (const uint32_t *)flat, cnt, rowoff1,

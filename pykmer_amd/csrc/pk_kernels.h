@@ -44,6 +44,7 @@ struct PartPlan {
     uint32_t n_wg0, G;       // walk workgroups and chunks per workgroup (rows of the level-1 histogram)
     uint64_t R2;             // records per level-2 workgroup
     uint32_t n_wg2_max;      // upper bound on level-2 workgroups
+    uint32_t dbg;            // PK_DEBUG_WALK ablation bits (timing diagnostics only; 0 in production)
 };
 struct PartWorkspace {       // byte offsets into one device allocation
     size_t flat, cnt, hist1, rowoff1, bucket_base, wg2_start, final_start, out1, hist2, rowoff2, out2, side, side_n;
