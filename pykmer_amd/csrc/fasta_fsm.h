@@ -29,11 +29,13 @@ enum : uint32_t { LS_START = 0, LS_HEADER = 1, LS_SEQ = 2 };
 __device__ __forceinline__ bool is_term(uint32_t c) { return c == 10u || c == 13u; }
 // str.strip() whitespace, ASCII subset (indexer.py:56): \t \n \v \f \r, FS GS RS US, space
 __device__ __forceinline__ bool is_ws(uint32_t c) { return c == 32u || (c - 9u) <= 4u || (c - 28u) <= 3u; }
-// CONV (indexer.py:36-41): 0..3 for ACGT/acgt, 4 otherwise
+// CONV (indexer.py:36-41): 0..3 for ACGT/acgt, 4 otherwise.  ASCII bits 1-2 of A,C,G,T are 00,01,11,10
+// (same for lower case), so code = b ^ (b >> 1); validity is a bit test in the 32-letter block.
 __device__ __forceinline__ uint32_t base_code(uint32_t c) {
-    uint32_t u = c | 0x20u;
-    uint32_t code = (u == 'a') ? 0u : (u == 'c') ? 1u : (u == 'g') ? 2u : (u == 't') ? 3u : 4u;
-    return code;
+    const uint32_t b = (c >> 1) & 3u;
+    const uint32_t code = b ^ (b >> 1);
+    const bool valid = (c >> 6) == 1u && ((0x0010008Au >> (c & 31u)) & 1u);
+    return valid ? code : 4u;
 }
 
 // ---------------------------------------------------------------- L1: line state -------------
@@ -97,6 +99,25 @@ __device__ __forceinline__ L2 l2_compose(const L2 &a, const L2 &b, uint32_t km1)
     c.flags = f;
     return c;
 }
+
+// Per-lane hand-off from the structure pass to the walk kernels: the lane's L2 prefix RELATIVE to its
+// chunk start (compose it behind the chunk's state to get the exact state), its incoming line state
+// and whether its piece needs the full byte machine.  16 bytes per 64-byte piece.
+struct LaneState {
+    uint32_t flags;   // L2 flags | ls_in << 16 | dirty << 18
+    uint32_t bits, rec, p_tail;
+};
+__device__ __forceinline__ LaneState lane_state_pack(const L2 &rel, uint32_t ls_in, bool dirty) {
+    LaneState o;
+    o.flags = rel.flags | (ls_in << 16) | (dirty ? (1u << 18) : 0u);
+    o.bits = rel.bits; o.rec = rel.rec; o.p_tail = (uint32_t)rel.p_tail;      // within one chunk: <= 16384
+    return o;
+}
+__device__ __forceinline__ L2 lane_state_l2(const LaneState &o) {
+    L2 r; r.flags = o.flags & 0xffffu; r.bits = o.bits; r.rec = o.rec; r.p_tail = o.p_tail; return r;
+}
+__device__ __forceinline__ uint32_t lane_state_ls(const LaneState &o) { return (o.flags >> 16) & 3u; }
+__device__ __forceinline__ bool lane_state_dirty(const LaneState &o) { return (o.flags >> 18) & 1u; }
 
 // ---- wave / workgroup exclusive scans (64-wide wavefronts, non-commutative operator) ----------
 __device__ __forceinline__ L1 wave_incl_scan_l1(L1 v, int lane) {
@@ -225,6 +246,45 @@ __device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb, bool &di
 }
 __device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb) {
     bool dirty;
+    return piece_l1(lds, nb, dirty);
+}
+
+// SWAR helpers: 0x80 in every byte of v that is zero / below n (n <= 128); exact, no cross-byte borrows
+__device__ __forceinline__ uint32_t swar_zero(uint32_t v) { return ~(((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v | 0x7f7f7f7fu); }
+__device__ __forceinline__ uint32_t swar_less(uint32_t v, uint32_t n_rep) {
+    return ~((((v & 0x7f7f7f7fu) | 0x80808080u) - n_rep) | v) & 0x80808080u;
+}
+
+// The same summary for a FULL 64-byte piece, four bytes per step: a piece without blanks (other than
+// terminators) and without '>' ends in LS_START if its last byte is a terminator and in LS_SEQ
+// otherwise.  Sets dirty (and returns 0) when the byte-wise machine is needed instead.
+__device__ __forceinline__ L1 piece_l1_swar(const uint8_t *lds, bool &dirty) {
+    const uint4 *mine = reinterpret_cast<const uint4 *>(lds + threadIdx.x * LDS_STRIDE);
+    uint32_t any_term = 0, bad = 0, last = 0;
+#pragma unroll
+    for (int q = 0; q < PIECE / 16; q++) {
+        const uint4 v = mine[q];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t t = swar_zero(w[j] ^ 0x0a0a0a0au) | swar_zero(w[j] ^ 0x0d0d0d0du);
+            any_term |= t;
+            bad |= (swar_less(w[j], 0x21212121u) & ~t) | swar_zero(w[j] ^ 0x3e3e3e3eu);   // blank that is no terminator, or '>'
+            last = t;
+        }
+    }
+    dirty = bad != 0;
+    return l1_make(any_term != 0, (last >> 31) ? (uint32_t)LS_START : (uint32_t)LS_SEQ);
+}
+
+// Wave-uniform front end used by the kernels: SWAR when every lane of the wave holds a full clean
+// piece, the byte-wise machine otherwise.
+__device__ __forceinline__ L1 piece_l1_auto(const uint8_t *lds, uint32_t nb, bool &dirty) {
+    if (__all(nb == (uint32_t)PIECE)) {
+        bool d;
+        L1 r = piece_l1_swar(lds, d);
+        if (__all(!d)) { dirty = false; return r; }
+    }
     return piece_l1(lds, nb, dirty);
 }
 

@@ -23,14 +23,16 @@ __global__ __launch_bounds__(WG) void k_chunk_l1(const uint8_t *__restrict__ fas
     uint64_t base = (uint64_t)blockIdx.x * CHUNK;
     stage_chunk(fasta, base, n_bytes, lds);
     __syncthreads();
-    L1 mine = piece_l1(lds, piece_len(base, n_bytes));
+    bool dirty;
+    L1 mine = piece_l1_auto(lds, piece_len(base, n_bytes), dirty);
     L1 total;
     wg_excl_scan_l1(mine, 0u, sh, &total);
     if (threadIdx.x == 0) chunk_l1[blockIdx.x] = total;
 }
 
 __global__ __launch_bounds__(WG) void k_chunk_l2(const uint8_t *__restrict__ fasta, uint64_t n_bytes,
-                                                 const L1 *__restrict__ chunk_l1_state, L2 *__restrict__ chunk_l2, uint32_t km1) {
+                                                 const L1 *__restrict__ chunk_l1_state, L2 *__restrict__ chunk_l2,
+                                                 LaneState *__restrict__ lane_state, uint32_t km1) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[WG * LDS_STRIDE];
     __shared__ L1 sh1[WG / 64];
     __shared__ L2 sh2[WG / 64];
@@ -40,13 +42,14 @@ __global__ __launch_bounds__(WG) void k_chunk_l2(const uint8_t *__restrict__ fas
     uint32_t nb = piece_len(base, n_bytes);
     L1 tot1;
     bool dirty;
-    L1 my1 = piece_l1(lds, nb, dirty);
+    L1 my1 = piece_l1_auto(lds, nb, dirty);
     L1 st1 = wg_excl_scan_l1(my1, chunk_l1_state[blockIdx.x], sh1, &tot1);
     const uint32_t ls_in = l1_kind(st1);
     const bool wave_clean = __all(!dirty && ls_in != LS_HEADER);          // wave-uniform choice of path
     L2 mine = wave_clean ? piece_l2_clean(lds, nb, ls_in, km1) : piece_l2(lds, nb, ls_in, km1);
     L2 total;
-    wg_excl_scan_l2(mine, l2_identity(), sh2, &total, km1);
+    L2 rel = wg_excl_scan_l2(mine, l2_identity(), sh2, &total, km1);     // prefix relative to the chunk start
+    lane_state[(uint64_t)blockIdx.x * WG + threadIdx.x] = lane_state_pack(rel, ls_in, dirty);
     if (threadIdx.x == 0) chunk_l2[blockIdx.x] = total;
 }
 
@@ -54,42 +57,45 @@ __global__ __launch_bounds__(WG) void k_chunk_l2(const uint8_t *__restrict__ fas
 // One workgroup of 1024 threads; n is at most a few hundred thousand chunk summaries.
 constexpr int SCAN_T = 1024;
 
+// Tiles of 1024 summaries: coalesced load, wave shuffle scan, 16 wave totals through LDS, running carry.
 __global__ __launch_bounds__(SCAN_T) void k_scan_l1(const L1 *__restrict__ in, uint32_t n, Carry *carry, L1 *__restrict__ out_state) {
     __shared__ L1 sh[SCAN_T / 64];
-    uint32_t per = (n + SCAN_T - 1) / SCAN_T, lo = threadIdx.x * per, hi = min(lo + per, n);
-    L1 acc = 0;
-    for (uint32_t i = lo; i < hi; i++) acc = l1_compose(acc, in[i]);
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    L1 inc = wave_incl_scan_l1(acc, lane);
-    if (lane == 63) sh[w] = inc;
-    __syncthreads();
-    L1 pre = carry->l1;
-    for (int i = 0; i < w; i++) pre = l1_compose(pre, sh[i]);
-    L1 up = __shfl_up(inc, 1, 64);
-    L1 run = (lane == 0) ? pre : l1_compose(pre, up);
-    L1 start = run;
-    for (uint32_t i = lo; i < hi; i++) { out_state[i] = run; run = l1_compose(run, in[i]); }
-    __syncthreads();
-    if (threadIdx.x == SCAN_T - 1) carry->l1 = l1_compose(start, acc);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    L1 run = carry->l1;                                    // state before the current tile (same in every thread)
+    for (uint32_t t0 = 0; t0 < n; t0 += SCAN_T) {
+        const uint32_t i = t0 + threadIdx.x;
+        const L1 mine = i < n ? in[i] : 0u;
+        const L1 inc = wave_incl_scan_l1(mine, lane);
+        if (lane == 63) sh[w] = inc;
+        __syncthreads();
+        L1 pre = run, tot = run;
+        for (int j = 0; j < SCAN_T / 64; j++) { if (j == w) pre = tot; tot = l1_compose(tot, sh[j]); }
+        const L1 up = __shfl_up(inc, 1, 64);
+        if (i < n) out_state[i] = (lane == 0) ? pre : l1_compose(pre, up);
+        run = tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) carry->l1 = run;
 }
 
 __global__ __launch_bounds__(SCAN_T) void k_scan_l2(const L2 *__restrict__ in, uint32_t n, Carry *carry, L2 *__restrict__ out_state, uint32_t km1) {
     __shared__ L2 sh[SCAN_T / 64];
-    uint32_t per = (n + SCAN_T - 1) / SCAN_T, lo = threadIdx.x * per, hi = min(lo + per, n);
-    L2 acc = l2_identity();
-    for (uint32_t i = lo; i < hi; i++) acc = l2_compose(acc, in[i], km1);
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    L2 inc = wave_incl_scan_l2(acc, lane, km1);
-    if (lane == 63) sh[w] = inc;
-    __syncthreads();
-    L2 pre = carry->l2;
-    for (int i = 0; i < w; i++) pre = l2_compose(pre, sh[i], km1);
-    L2 up = shfl_up_l2(inc, 1);
-    L2 run = (lane == 0) ? pre : l2_compose(pre, up, km1);
-    L2 start = run;
-    for (uint32_t i = lo; i < hi; i++) { out_state[i] = run; run = l2_compose(run, in[i], km1); }
-    __syncthreads();
-    if (threadIdx.x == SCAN_T - 1) { carry->l2 = l2_compose(start, acc, km1); carry->n_recs = carry->l2.rec; }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    L2 run = carry->l2;
+    for (uint32_t t0 = 0; t0 < n; t0 += SCAN_T) {
+        const uint32_t i = t0 + threadIdx.x;
+        const L2 mine = i < n ? in[i] : l2_identity();
+        const L2 inc = wave_incl_scan_l2(mine, lane, km1);
+        if (lane == 63) sh[w] = inc;
+        __syncthreads();
+        L2 pre = run, tot = run;
+        for (int j = 0; j < SCAN_T / 64; j++) { if (j == w) pre = tot; tot = l2_compose(tot, sh[j], km1); }
+        const L2 up = shfl_up_l2(inc, 1);
+        if (i < n) out_state[i] = (lane == 0) ? pre : l2_compose(pre, up, km1);
+        run = tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { carry->l2 = run; carry->n_recs = run.rec; }
 }
 
 // ------------------------------------------------------------------ k-mer walk -----------------
@@ -112,43 +118,30 @@ struct DirectSink {
 
 template <typename KT>
 __global__ __launch_bounds__(WG) void k_count(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
-                                              const L1 *__restrict__ chunk_l1_state, const L2 *__restrict__ chunk_l2_state,
+                                              const LaneState *__restrict__ lane_state, const L2 *__restrict__ chunk_l2_state,
                                               uint32_t k, uint32_t *__restrict__ table32, DevRec *__restrict__ recs,
                                               uint64_t recs_cap, Carry *carry) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[WG * LDS_STRIDE];
-    __shared__ L1 sh1[WG / 64];
-    __shared__ L2 sh2[WG / 64];
+    __shared__ RecAcc racc;
     const uint32_t km1 = k - 1;
     uint64_t base = (uint64_t)blockIdx.x * CHUNK;
-    stage_chunk(fasta, base, n_bytes, lds);
-    __syncthreads();
-    uint32_t nb = piece_len(base, n_bytes);
-    L1 tot1;
-    bool dirty;
-    L1 my1 = piece_l1(lds, nb, dirty);
-    L1 st1 = wg_excl_scan_l1(my1, chunk_l1_state[blockIdx.x], sh1, &tot1);
-    uint32_t ls = l1_kind(st1);
-    const bool l2_clean = __all(!dirty && ls != LS_HEADER);
-    L2 tot2;
-    L2 st2 = wg_excl_scan_l2(l2_clean ? piece_l2_clean(lds, nb, ls, km1) : piece_l2(lds, nb, ls, km1),
-                             chunk_l2_state[blockIdx.x], sh2, &tot2, km1);
-
-    // exact parser state at this lane's first byte
-    __shared__ RecAcc racc;
     recacc_init(racc);
+    stage_chunk(fasta, base, n_bytes, lds);
     __syncthreads();
     recacc_retarget(racc, chunk_l2_state[blockIdx.x].rec, recs, recs_cap);
     __syncthreads();
+    const uint32_t nb = piece_len(base, n_bytes);
+    // exact parser state at this lane's first byte: chunk state . lane prefix (from k_chunk_l2)
+    const LaneState lst = lane_state[(uint64_t)blockIdx.x * WG + threadIdx.x];
+    const L2 st2 = l2_compose(chunk_l2_state[blockIdx.x], lane_state_l2(lst), km1);
+    const uint32_t ls = lane_state_ls(lst);
     Walker<KT> wk;
     wk.setup(k, recs, recs_cap, &racc);
     wk.begin(ls, st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
     DirectSink sink;
     sink.init(table32);
-    if (__all(!dirty && ls != LS_HEADER && st2.p_tail == 0)) {
-        for_each_byte(lds, nb, [&](uint32_t, uint32_t c, bool act) {
-            KT canon;
-            if (wk.step_clean(c, act, canon)) sink.emit((uint64_t)canon);
-        });
+    if (__all(!lane_state_dirty(lst) && ls != LS_HEADER && st2.p_tail == 0)) {
+        wk.walk_clean(lds, nb, [&](bool has, KT canon) { if (has) sink.emit((uint64_t)canon); });
     } else {
         for_each_byte(lds, nb, [&](uint32_t i, uint32_t c, bool act) {
             KT canon;
@@ -232,18 +225,19 @@ void launch_chunk_l1(const uint8_t *fasta, uint64_t n, L1 *chunk_l1, uint32_t n_
 void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_l1, dim3(1), dim3(SCAN_T), 0, s, in, n_chunks, carry, out);
 }
-void launch_chunk_l2(const uint8_t *fasta, uint64_t n, const L1 *st1, L2 *chunk_l2, uint32_t n_chunks, uint32_t k, hipStream_t s) {
-    hipLaunchKernelGGL(k_chunk_l2, dim3(n_chunks), dim3(WG), 0, s, fasta, n, st1, chunk_l2, k - 1);
+void launch_chunk_l2(const uint8_t *fasta, uint64_t n, const L1 *st1, L2 *chunk_l2, LaneState *lane_state, uint32_t n_chunks, uint32_t k,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_chunk_l2, dim3(n_chunks), dim3(WG), 0, s, fasta, n, st1, chunk_l2, lane_state, k - 1);
 }
 void launch_scan_l2(const L2 *in, uint32_t n_chunks, Carry *carry, L2 *out, uint32_t k, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_l2, dim3(1), dim3(SCAN_T), 0, s, in, n_chunks, carry, out, k - 1);
 }
-void launch_count(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const L1 *st1, const L2 *st2, uint32_t n_chunks,
+void launch_count(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, uint32_t n_chunks,
                   uint32_t k, uint32_t *table32, DevRec *recs, uint64_t recs_cap, Carry *carry, hipStream_t s) {
     if (k <= 15)
-        hipLaunchKernelGGL(k_count<uint32_t>, dim3(n_chunks), dim3(WG), 0, s, fasta, n, stream_off, st1, st2, k, table32, recs, recs_cap, carry);
+        hipLaunchKernelGGL(k_count<uint32_t>, dim3(n_chunks), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, k, table32, recs, recs_cap, carry);
     else
-        hipLaunchKernelGGL(k_count<uint64_t>, dim3(n_chunks), dim3(WG), 0, s, fasta, n, stream_off, st1, st2, k, table32, recs, recs_cap, carry);
+        hipLaunchKernelGGL(k_count<uint64_t>, dim3(n_chunks), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, k, table32, recs, recs_cap, carry);
 }
 static uint32_t stream_grid(uint64_t items_per_thread_units) {
     uint64_t g = (items_per_thread_units + WG - 1) / WG;

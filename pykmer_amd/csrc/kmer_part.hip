@@ -37,11 +37,13 @@ constexpr int TILE = SC_T * SC_PER;  // 16384 records per tile = one FASTA chunk
 // ------------------------------------------------------------------ hot keys ---------------------
 // Tandem repeats (poly-A/T, (AT)n, (AAG)n ...) put tens of millions of identical canonical k-mers on a
 // handful of addresses; routed like everything else they would all land in ONE final bucket, i.e. on
-// one CU.  Each lane therefore keeps the last four distinct k-mers it produced with run counts; only
-// entries seen once go into the record stream, entries seen >= 2 times are privatised in a per-
-// workgroup LDS hash table (addr -> count) that is appended to a global side list when the workgroup
-// finishes (or the table half fills).  k_apply_side folds the side list into the finished u8 table
-// with saturating CAS adds -- a few thousand entries instead of 10^7..10^8 records.
+// one CU.  Each lane therefore remembers its last three distinct k-mers (periods 1-3 cover poly-N,
+// dinucleotide and trinucleotide repeats): a k-mer is emitted the first time it is seen, repeats while
+// it is remembered only bump a lane counter, and evicted counters are tallied in a per-workgroup LDS
+// hash table (addr -> count; lanes holding the same address are merged with ballot + readlane first),
+// which is appended to a global side list when the workgroup finishes (or the table half fills).
+// k_apply_side folds the side list into the finished u8 table with saturating CAS adds -- a few
+// thousand entries instead of 10^7..10^8 records.
 constexpr uint32_t HOT_SLOTS = 1024;     // per-workgroup LDS hash slots
 constexpr uint32_t HOT_PROBES = 16;
 constexpr uint32_t SIDE_CNT_BITS = 28;   // side entry = (addr << 28) | count
@@ -74,6 +76,25 @@ __device__ __forceinline__ void hot_insert(HotTable &H, uint64_t addr, uint32_t 
     side_append_one(side, side_n, side_cap, addr, cnt);          // table crowded: straight to the side list
 }
 
+// Whole wave (uniform call): every lane with n > 0 contributes (addr, n); lanes holding the same addr
+// are summed with ballot + readlane and inserted once.  Deliberately not inlined: it runs a few times
+// per piece at most and would otherwise be replicated through the unrolled walk loop.
+__device__ __noinline__ void hot_insert_wave(HotTable *H, unsigned long long addr, uint32_t n, unsigned long long *side,
+                                             unsigned long long *side_n, uint64_t side_cap) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long pending = __ballot(n != 0u);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const unsigned long long a = __shfl(addr, leader, 64);
+        const bool mine = n != 0u && addr == a;
+        const unsigned long long same = __ballot(mine);
+        uint32_t tot = mine ? n : 0u;
+        for (int d = 32; d; d >>= 1) tot += __shfl_xor(tot, d, 64);
+        if (lane == leader) hot_insert(*H, a, tot, side, side_n, side_cap);
+        pending &= ~same;
+    }
+}
+
 // all threads of the workgroup; appends every occupied slot to the side list and clears the table
 __device__ __forceinline__ void hot_flush(HotTable &H, unsigned long long *side, unsigned long long *side_n, uint64_t side_cap) {
     __syncthreads();
@@ -100,14 +121,12 @@ __device__ __forceinline__ void hot_flush(HotTable &H, unsigned long long *side,
 // ------------------------------------------------------------------ K0: walk -> flat records ----
 template <typename KT, typename REC0>
 __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
-                                                  const L1 *__restrict__ chunk_l1_state, const L2 *__restrict__ chunk_l2_state,
+                                                  const LaneState *__restrict__ lane_state, const L2 *__restrict__ chunk_l2_state,
                                                   PartPlan pl, REC0 *__restrict__ flat, uint32_t *__restrict__ cnt,
                                                   uint32_t *__restrict__ hist1_rows, DevRec *__restrict__ recs, uint64_t recs_cap,
                                                   Carry *carry, unsigned long long *__restrict__ side,
                                                   unsigned long long *__restrict__ side_n, uint64_t side_cap) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[WG * LDS_STRIDE];
-    __shared__ L1 sh1[WG / 64];
-    __shared__ L2 sh2[WG / 64];
     __shared__ uint32_t hist1[512];
     __shared__ HotTable hot;
     for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += WG) { hot.key[i] = 0ull; hot.val[i] = 0u; }
@@ -128,22 +147,15 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
         stage_chunk(fasta, base, n_bytes, lds);
         __syncthreads();
         const uint32_t nb = piece_len(base, n_bytes);
-        L1 tot1;
-        bool dirty;
-        L1 my1 = piece_l1(lds, nb, dirty);
-        L1 st1 = wg_excl_scan_l1(my1, chunk_l1_state[c], sh1, &tot1);
-        const uint32_t ls_in = l1_kind(st1);
-        const bool l2_clean = __all(!dirty && ls_in != LS_HEADER);        // wave-uniform
-        L2 tot2;
-        L2 st2 = wg_excl_scan_l2(l2_clean ? piece_l2_clean(lds, nb, ls_in, km1) : piece_l2(lds, nb, ls_in, km1),
-                                 chunk_l2_state[c], sh2, &tot2, km1);
-        const bool walk_clean = __all(!dirty && ls_in != LS_HEADER && st2.p_tail == 0);
+        // exact parser state at this lane's first byte: chunk state . lane prefix (both from the structure pass)
+        const LaneState lst = lane_state[(uint64_t)c * WG + threadIdx.x];
+        const L2 st2 = l2_compose(chunk_l2_state[c], lane_state_l2(lst), km1);
+        const uint32_t ls_in = lane_state_ls(lst);
+        const bool walk_clean = __all(!lane_state_dirty(lst) && ls_in != LS_HEADER && st2.p_tail == 0);
         wk.begin(ls_in, st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
 
         REC0 *region = flat + ((uint64_t)c * (WG / 64) + wave) * SUB;
         uint32_t wcount = 0;                               // wave-uniform
-        KT a0 = 0, a1 = 0, a2 = 0, a3 = 0;                 // last four distinct canonical k-mers of this lane
-        uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;           // ... and how often each was seen
         // wave-uniform call: ballot-compact this step's records into the wave's region (coalesced store)
         const uint32_t dbg = pl.dbg;
         auto wave_emit = [&](bool e, KT a) {
@@ -155,27 +167,25 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
             }
             wcount += __popcll(m);
         };
+        // The lane remembers its last three distinct k-mers.  A k-mer is emitted the first time it is seen;
+        // seeing it again while remembered (tandem repeats of period 1-3: the contended buckets) only
+        // bumps a counter, which goes to the workgroup's LDS table when the entry is evicted or the piece
+        // ends.  Either route counts each k-mer exactly once.
+        KT a1 = ~(KT)0, a2 = ~(KT)0, a3 = ~(KT)0;
+        uint32_t n1 = 0, n2 = 0, n3 = 0;
         auto route = [&](bool has, KT canon) {
-            if (dbg & 1u) { wave_emit(has, canon); return; }
-            // lane-local run merging: only k-mers seen once among the last four distinct ones are emitted
-            const bool m0 = has && c0 && canon == a0, m1 = has && c1 && canon == a1;
-            const bool m2 = has && c2 && canon == a2, m3 = has && c3 && canon == a3;
-            const bool miss = has && !(m0 || m1 || m2 || m3);
-            c0 += m0 ? 1u : 0u; c1 += (!m0 && m1) ? 1u : 0u;
-            c2 += (!m0 && !m1 && m2) ? 1u : 0u; c3 += (!m0 && !m1 && !m2 && m3) ? 1u : 0u;
-            const bool emit = miss && c3 == 1u;
-            const KT ea = a3;
-            if (miss && c3 >= 2u) hot_insert(hot, (uint64_t)a3, c3, side, side_n, side_cap);
-            if (miss) { a3 = a2; c3 = c2; a2 = a1; c2 = c1; a1 = a0; c1 = c0; a0 = canon; c0 = 1u; }
-            wave_emit(emit, ea);
+            const bool m1 = has && canon == a1, m2 = has && canon == a2, m3 = has && canon == a3;
+            const bool miss = has && !(m1 || m2 || m3);
+            n1 += m1 ? 1u : 0u; n2 += (m2 && !m1) ? 1u : 0u; n3 += (m3 && !m1 && !m2) ? 1u : 0u;
+            const uint32_t ev_n = miss ? n3 : 0u;
+            const KT ev_a = a3;
+            if (miss) { a3 = a2; n3 = n2; a2 = a1; n2 = n1; a1 = canon; n1 = 0u; }
+            wave_emit((dbg & 1u) ? has : miss, canon);
+            if (__ballot(ev_n != 0u)) hot_insert_wave(&hot, (unsigned long long)ev_a, ev_n, side, side_n, side_cap);
         };
         if (dbg & 8u) {
         } else if (walk_clean) {                             // the common case: plain sequence lines
-            for_each_byte(lds, nb, [&](uint32_t, uint32_t ch, bool act) {
-                KT canon;
-                const bool has = wk.step_clean(ch, act, canon);
-                route(has, canon);
-            });
+            wk.walk_clean(lds, nb, route);
         } else {
             for_each_byte(lds, nb, [&](uint32_t i, uint32_t ch, bool act) {
                 KT canon;
@@ -183,16 +193,9 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
                 route(has, canon);
             });
         }
-        // drain the lane caches (oldest first)
-        {
-            KT fa[4] = {a3, a2, a1, a0};
-            uint32_t fc[4] = {c3, c2, c1, c0};
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                if (fc[e] >= 2u) hot_insert(hot, (uint64_t)fa[e], fc[e], side, side_n, side_cap);
-                wave_emit(fc[e] == 1u, fa[e]);
-            }
-        }
+        hot_insert_wave(&hot, (unsigned long long)a1, n1, side, side_n, side_cap);     // drain the lane's entries
+        hot_insert_wave(&hot, (unsigned long long)a2, n2, side, side_n, side_cap);
+        hot_insert_wave(&hot, (unsigned long long)a3, n3, side, side_n, side_cap);
         wk.flush_rec_wave();
         if (lane == 0) cnt[c * (WG / 64) + wave] = wcount;
         __syncthreads();                                   // pieces consumed; LDS may be restaged
@@ -208,23 +211,40 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
 // ------------------------------------------------------------------ K1: level-1 column scan -----
 // One workgroup, one thread per digit.  rowoff[w][d] = records of digit d written by rows < w;
 // bucket_base[d] = start of bucket d; level-2 rows: bucket d gets ceil(n_d / R2) workgroups.
-__global__ __launch_bounds__(512) void k_rows1_scan(const uint32_t *__restrict__ hist_rows, uint32_t *__restrict__ rowoff, PartPlan pl,
-                                                    uint32_t *__restrict__ bucket_base, uint32_t *__restrict__ wg2_start,
-                                                    uint32_t *__restrict__ final_start) {
+__global__ __launch_bounds__(1024) void k_rows1_scan(const uint32_t *__restrict__ hist_rows, uint32_t *__restrict__ rowoff, PartPlan pl,
+                                                     uint32_t *__restrict__ bucket_base, uint32_t *__restrict__ wg2_start,
+                                                     uint32_t *__restrict__ final_start) {
+    __shared__ uint32_t part[1024];                        // [P][B1] partial column sums, then their prefixes
     __shared__ uint32_t tot[512];
-    const uint32_t d = threadIdx.x;
+    const uint32_t B1 = pl.B1;
+    uint32_t P = 1024u / B1;                               // row groups scanned in parallel
+    if (P > 32u) P = 32u;
+    const uint32_t d = threadIdx.x % B1, g = threadIdx.x / B1;
+    const uint32_t rows_per = (pl.n_wg0 + P - 1) / P;
+    const uint32_t r_lo = g * rows_per, r_hi = min(r_lo + rows_per, pl.n_wg0);
+    const bool live = g < P;
     uint32_t acc = 0;
-    if (d < pl.B1)
-        for (uint32_t w = 0; w < pl.n_wg0; w++) {
-            uint32_t v = hist_rows[(uint64_t)w * pl.B1 + d];
-            rowoff[(uint64_t)w * pl.B1 + d] = acc;
-            acc += v;
-        }
-    tot[d] = d < pl.B1 ? acc : 0;
+    if (live)
+        for (uint32_t w = r_lo; w < r_hi; w++) acc += hist_rows[(uint64_t)w * B1 + d];
+    if (live) part[g * B1 + d] = acc;
     __syncthreads();
-    if (d == 0) {
+    if (g == 0) {                                          // one thread per digit: prefix over the P groups
+        uint32_t a = 0;
+        for (uint32_t q = 0; q < P; q++) { uint32_t v = part[q * B1 + d]; part[q * B1 + d] = a; a += v; }
+        tot[d] = a;
+    }
+    __syncthreads();
+    if (live) {
+        uint32_t a = part[g * B1 + d];
+        for (uint32_t w = r_lo; w < r_hi; w++) {
+            uint32_t v = hist_rows[(uint64_t)w * B1 + d];
+            rowoff[(uint64_t)w * B1 + d] = a;
+            a += v;
+        }
+    }
+    if (threadIdx.x == 0) {
         uint32_t a = 0, wgs = 0;
-        for (uint32_t i = 0; i < pl.B1; i++) {
+        for (uint32_t i = 0; i < B1; i++) {
             uint32_t n = tot[i];
             bucket_base[i] = a;
             wg2_start[i] = wgs;
@@ -232,9 +252,9 @@ __global__ __launch_bounds__(512) void k_rows1_scan(const uint32_t *__restrict__
             a += n;
             wgs += (uint32_t)((n + pl.R2 - 1) / pl.R2);
         }
-        bucket_base[pl.B1] = a;
-        wg2_start[pl.B1] = wgs;
-        if (pl.b2 == 0) final_start[pl.B1] = a;
+        bucket_base[B1] = a;
+        wg2_start[B1] = wgs;
+        if (pl.b2 == 0) final_start[B1] = a;
     }
 }
 
@@ -461,14 +481,20 @@ __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restric
         for (uint32_t i = p0 + threadIdx.x * 8; i < p1; i += SC_T * 8) {
             uint4 v = *reinterpret_cast<const uint4 *>(recs + i);
             uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            // the lane's 8 records, equal neighbours merged (what is left of tandem runs arrives back to back)
+            uint32_t pa = 0, pn = 0;
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-                uint32_t idx = i + q;
-                if (idx >= start && idx < end) {
-                    uint32_t a = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-                    atomicAdd(&cnt[a >> 1], 1u << (16 * (a & 1)));
+                const uint32_t idx = i + q;
+                const bool in = idx >= start && idx < end;
+                const uint32_t a = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                if (in && pn && a == pa) pn++;
+                else {
+                    if (pn) atomicAdd(&cnt[pa >> 1], pn << (16 * (pa & 1)));
+                    pa = a; pn = in ? 1u : 0u;
                 }
             }
+            if (pn) atomicAdd(&cnt[pa >> 1], pn << (16 * (pa & 1)));
         }
         __syncthreads();
         if (p1 < end) {                                                  // more to come: clamp so nothing can overflow
@@ -594,13 +620,13 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
     lay->hist2 = o; o += up((size_t)pl.n_wg2_max * pl.B2 * 4);
     lay->rowoff2 = o; o += up((size_t)pl.n_wg2_max * pl.B2 * 4);
     lay->out2 = o; o += up(pl.b2 ? (size_t)(n_bytes + 64) * 2 : 256);
-    lay->side_cap = n_bytes / 2 + 16;                      // every side entry stands for >= 2 k-mers
+    lay->side_cap = n_bytes + 16;                          // every side entry stands for >= 1 k-mer
     lay->side = o; o += up((size_t)lay->side_cap * 8);
     lay->side_n = o; o += 256;
     return o;
 }
 
-int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const L1 *st1, const L2 *st2, const PartPlan &pl,
+int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, const PartPlan &pl,
                        uint8_t *ws, const PartWorkspace &lay, uint8_t *table8, DevRec *recs, uint64_t recs_cap, Carry *carry,
                        hipStream_t s, hipEvent_t ev_walk_end, hipEvent_t ev_part_end) {
     uint32_t *cnt = (uint32_t *)(ws + lay.cnt), *hist1 = (uint32_t *)(ws + lay.hist1), *rowoff1 = (uint32_t *)(ws + lay.rowoff1);
@@ -614,10 +640,10 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     hipFuncSetAttribute((const void *)k_bucket_count, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (hipMemsetAsync(side_n, 0, 8, s) != hipSuccess) return -2;
     if (pl.k <= 15) {
-        hipLaunchKernelGGL((k_walk_flat<uint32_t, uint32_t>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, st1, st2, pl,
+        hipLaunchKernelGGL((k_walk_flat<uint32_t, uint32_t>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, pl,
                            (uint32_t *)flat, cnt, hist1, recs, recs_cap, carry, side, side_n, lay.side_cap);
     } else {
-        hipLaunchKernelGGL((k_walk_flat<uint64_t, uint64_t>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, st1, st2, pl,
+        hipLaunchKernelGGL((k_walk_flat<uint64_t, uint64_t>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, pl,
                            (uint64_t *)flat, cnt, hist1, recs, recs_cap, carry, side, side_n, lay.side_cap);
     }
     if (ev_walk_end) hipEventRecord(ev_walk_end, s);
@@ -625,7 +651,7 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
         if (ev_part_end) hipEventRecord(ev_part_end, s);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
-    hipLaunchKernelGGL(k_rows1_scan, dim3(1), dim3(512), 0, s, hist1, rowoff1, pl, bucket_base, wg2_start, final_start);
+    hipLaunchKernelGGL(k_rows1_scan, dim3(1), dim3(1024), 0, s, hist1, rowoff1, pl, bucket_base, wg2_start, final_start);
     if (pl.k <= 15)
         hipLaunchKernelGGL(k_scatter1<uint32_t>, dim3(pl.n_wg0), dim3(SC_T), sizeof(ScatterLds), s, (const uint32_t *)flat, cnt, rowoff1,
                            bucket_base, pl, out1);

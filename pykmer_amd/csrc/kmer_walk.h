@@ -110,22 +110,41 @@ struct Walker {
         if (seq_acc | kmer_acc | name_end) flush_rec();
     }
 
-    // One byte of a CLEAN piece (sequence characters and line terminators only, no pending blanks,
-    // not inside a header): the line/record machinery drops out.
-    __device__ __forceinline__ bool step_clean(uint32_t c, bool act, KT &canon) {
-        const bool seqchar = act && !is_term(c);
-        seq_acc += seqchar ? 1ull : 0ull;
-        const uint32_t code = base_code(c);
-        const bool valid = seqchar && code < 4u;
-        const KT nf = (KT)(((fwd << 2) | (KT)(code & 3u)) & mask);
-        const KT nr = (KT)((rev >> 2) | ((KT)(3u - (code & 3u)) << top));
-        fwd = valid ? nf : fwd;
-        rev = valid ? nr : rev;
-        run = valid ? (run < k ? run + 1 : run) : (seqchar ? 0u : run);
-        const bool has = valid && run == k && rec != 0;
-        kmer_acc += has ? 1ull : 0ull;
-        canon = fwd < rev ? fwd : rev;
-        return has;
+    // A whole CLEAN piece (sequence characters and line terminators only, no pending blanks, not
+    // inside a header): the line/record machinery drops out and the loop is kept deliberately lean --
+    // 32-bit counters, integer flags, 4 bytes per iteration with constant shifts.  `sink(has, canon)`
+    // is called once per byte slot in wave-uniform control flow.
+    template <class Sink>
+    __device__ __forceinline__ void walk_clean(const uint8_t *lds, uint32_t nb, Sink &&sink) {
+        const uint4 *mine = reinterpret_cast<const uint4 *>(lds + threadIdx.x * LDS_STRIDE);
+        KT f = fwd, r = rev;
+        uint32_t rn = run, n_seq = 0, n_kmer = 0;
+        const uint32_t kk = k, live = rec != 0 ? 1u : 0u;
+        const uint32_t *words = reinterpret_cast<const uint32_t *>(mine);
+#pragma unroll 1
+        for (uint32_t q = 0; q < (uint32_t)PIECE / 4u; q++) {            // one dword per iteration: small code, constant shifts
+            const uint32_t wq = words[q];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++) {
+                uint32_t c = (wq >> (8u * j)) & 0xffu;
+                c = (q * 4u + j < nb) ? c : 10u;                         // past the end: behaves like a terminator
+                const uint32_t seq = (c != 10u && c != 13u) ? 1u : 0u;
+                const uint32_t b = (c >> 1) & 3u, code = b ^ (b >> 1);
+                const uint32_t valid = (c >> 6) == 1u ? ((0x0010008Au >> (c & 31u)) & 1u) : 0u;
+                const KT nf = (KT)(((f << 2) | (KT)code) & mask);        // indexer.py:149
+                const KT nr = (KT)((r >> 2) | ((KT)(3u - code) << top)); // indexer.py:150
+                f = valid ? nf : f;
+                r = valid ? nr : r;
+                const uint32_t grown = rn < kk ? rn + 1u : rn;
+                rn = valid ? grown : (seq ? 0u : rn);
+                const bool has = (valid & live) != 0u && rn == kk;
+                n_seq += seq;
+                n_kmer += has ? 1u : 0u;
+                sink(has, (KT)(f < r ? f : r));
+            }
+        }
+        fwd = f; rev = r; run = rn;
+        seq_acc += n_seq; kmer_acc += n_kmer;
     }
 
     // One byte.  Returns true when a valid window ends here; canon = min(fwd, rev) (indexer.py:341).

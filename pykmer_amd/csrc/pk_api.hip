@@ -93,6 +93,7 @@ struct pk_indexer {
     uint64_t recs_cap = 0;
     L1 *c_l1 = nullptr, *c_l1s = nullptr;
     L2 *c_l2 = nullptr, *c_l2s = nullptr;
+    LaneState *lane_state = nullptr;   // per 64-byte piece: start state relative to its chunk
     uint32_t chunk_cap = 0;
     uint8_t *staging = nullptr;      // device copy of host-fed bytes
     uint64_t staging_cap = 0;
@@ -135,7 +136,7 @@ extern "C" void pk_indexer_destroy(pk_indexer *ix) {
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
     hipFree(ix->table32); hipFree(ix->table8); hipFree(ix->carry); hipFree(ix->hist); hipFree(ix->recs);
-    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->staging); hipFree(ix->ws);
+    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state); hipFree(ix->staging); hipFree(ix->ws);
     for (auto &e : ix->ev) if (e) hipEventDestroy(e);
     if (ix->stream) hipStreamDestroy(ix->stream);
     delete ix;
@@ -178,12 +179,13 @@ extern "C" int pk_indexer_reset(pk_indexer *ix) {
 
 static int ensure_chunks(pk_indexer *ix, uint32_t n_chunks) {
     if (n_chunks <= ix->chunk_cap) return PK_OK;
-    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s);
-    ix->c_l1 = ix->c_l1s = nullptr; ix->c_l2 = ix->c_l2s = nullptr; ix->chunk_cap = 0;
+    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state);
+    ix->c_l1 = ix->c_l1s = nullptr; ix->c_l2 = ix->c_l2s = nullptr; ix->lane_state = nullptr; ix->chunk_cap = 0;
     HIPCHK(hipMalloc(&ix->c_l1, n_chunks * sizeof(L1)));
     HIPCHK(hipMalloc(&ix->c_l1s, n_chunks * sizeof(L1)));
     HIPCHK(hipMalloc(&ix->c_l2, n_chunks * sizeof(L2)));
     HIPCHK(hipMalloc(&ix->c_l2s, n_chunks * sizeof(L2)));
+    HIPCHK(hipMalloc(&ix->lane_state, (size_t)n_chunks * WG * sizeof(LaneState)));
     ix->chunk_cap = n_chunks;
     return PK_OK;
 }
@@ -222,7 +224,7 @@ extern "C" int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uin
     HIPCHK(hipEventRecord(ix->ev[0], ix->stream));
     launch_chunk_l1(f, n_bytes, ix->c_l1, n_chunks, ix->stream);
     launch_scan_l1(ix->c_l1, n_chunks, ix->carry, ix->c_l1s, ix->stream);
-    launch_chunk_l2(f, n_bytes, ix->c_l1s, ix->c_l2, n_chunks, (uint32_t)ix->k, ix->stream);
+    launch_chunk_l2(f, n_bytes, ix->c_l1s, ix->c_l2, ix->lane_state, n_chunks, (uint32_t)ix->k, ix->stream);
     launch_scan_l2(ix->c_l2, n_chunks, ix->carry, ix->c_l2s, (uint32_t)ix->k, ix->stream);
     HIPCHK(hipEventRecord(ix->ev[1], ix->stream));
     uint64_t n_recs = 0;
@@ -234,7 +236,7 @@ extern "C" int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uin
     float a = 0, b = 0, c = 0, d = 0;
     if (ix->direct) {
         HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
-        launch_count(f, n_bytes, ix->bytes_fed, ix->c_l1s, ix->c_l2s, n_chunks, (uint32_t)ix->k, ix->table32, ix->recs, ix->recs_cap,
+        launch_count(f, n_bytes, ix->bytes_fed, ix->lane_state, ix->c_l2s, n_chunks, (uint32_t)ix->k, ix->table32, ix->recs, ix->recs_cap,
                      ix->carry, ix->stream);
         HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
         HIPCHK(hipGetLastError());
@@ -249,7 +251,7 @@ extern "C" int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uin
             ix->ws_cap = need;
         }
         HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
-        if (launch_partitioned(f, n_bytes, ix->bytes_fed, ix->c_l1s, ix->c_l2s, pl, ix->ws, lay, ix->table8, ix->recs, ix->recs_cap,
+        if (launch_partitioned(f, n_bytes, ix->bytes_fed, ix->lane_state, ix->c_l2s, pl, ix->ws, lay, ix->table8, ix->recs, ix->recs_cap,
                                ix->carry, ix->stream, ix->ev[3], ix->ev[8]))
             return fail(PK_ERR_HIP, "partition pipeline launch failed: %s", hipGetErrorString(hipGetLastError()));
         HIPCHK(hipEventRecord(ix->ev[9], ix->stream));
