@@ -54,48 +54,90 @@ __global__ __launch_bounds__(WG) void k_chunk_l2(const uint8_t *__restrict__ fas
 }
 
 // ------------------------------------------------------------------ grid-level scans -----------
-// One workgroup of 1024 threads; n is at most a few hundred thousand chunk summaries.
+// Three tiny launches per level instead of one latency-bound workgroup: (1) every 1024-summary tile is
+// reduced by its own workgroup, (2) one workgroup scans the <= a few hundred tile totals behind the
+// carried stream state, (3) every tile is scanned again behind its seed and written out.
 constexpr int SCAN_T = 1024;
 
-// Tiles of 1024 summaries: coalesced load, wave shuffle scan, 16 wave totals through LDS, running carry.
-__global__ __launch_bounds__(SCAN_T) void k_scan_l1(const L1 *__restrict__ in, uint32_t n, Carry *carry, L1 *__restrict__ out_state) {
-    __shared__ L1 sh[SCAN_T / 64];
+template <typename S, class Compose, class Shfl>
+__device__ __forceinline__ S tile_scan(const S &mine, const S &seed, S *sh, S *total, Compose compose, Shfl shfl_up1) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    L1 run = carry->l1;                                    // state before the current tile (same in every thread)
-    for (uint32_t t0 = 0; t0 < n; t0 += SCAN_T) {
+    S inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        S o = shfl_up1(inc, d);
+        if (lane >= d) inc = compose(o, inc);
+    }
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    S pre = seed, tot = seed;
+    for (int j = 0; j < SCAN_T / 64; j++) { if (j == w) pre = tot; tot = compose(tot, sh[j]); }
+    *total = tot;
+    S up = shfl_up1(inc, 1);
+    return lane == 0 ? pre : compose(pre, up);
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_l1_reduce(const L1 *__restrict__ in, uint32_t n, L1 *__restrict__ tile_tot) {
+    __shared__ L1 sh[SCAN_T / 64];
+    const uint32_t i = blockIdx.x * SCAN_T + threadIdx.x;
+    L1 tot;
+    tile_scan<L1>(i < n ? in[i] : 0u, 0u, sh, &tot, [](L1 a, L1 b) { return l1_compose(a, b); }, [](L1 v, int d) { return (L1)__shfl_up(v, d, 64); });
+    if (threadIdx.x == 0) tile_tot[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(SCAN_T) void k_scan_l1_tiles(L1 *__restrict__ tile_tot, uint32_t n_tiles, Carry *carry) {
+    __shared__ L1 sh[SCAN_T / 64];
+    L1 run = carry->l1;
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += SCAN_T) {
         const uint32_t i = t0 + threadIdx.x;
-        const L1 mine = i < n ? in[i] : 0u;
-        const L1 inc = wave_incl_scan_l1(mine, lane);
-        if (lane == 63) sh[w] = inc;
-        __syncthreads();
-        L1 pre = run, tot = run;
-        for (int j = 0; j < SCAN_T / 64; j++) { if (j == w) pre = tot; tot = l1_compose(tot, sh[j]); }
-        const L1 up = __shfl_up(inc, 1, 64);
-        if (i < n) out_state[i] = (lane == 0) ? pre : l1_compose(pre, up);
+        L1 tot;
+        L1 ex = tile_scan<L1>(i < n_tiles ? tile_tot[i] : 0u, run, sh, &tot, [](L1 a, L1 b) { return l1_compose(a, b); },
+                              [](L1 v, int d) { return (L1)__shfl_up(v, d, 64); });
+        if (i < n_tiles) tile_tot[i] = ex;                 // now: the state before the tile
         run = tot;
         __syncthreads();
     }
     if (threadIdx.x == 0) carry->l1 = run;
 }
+__global__ __launch_bounds__(SCAN_T) void k_scan_l1_apply(const L1 *__restrict__ in, uint32_t n, const L1 *__restrict__ tile_seed,
+                                                          L1 *__restrict__ out_state) {
+    __shared__ L1 sh[SCAN_T / 64];
+    const uint32_t i = blockIdx.x * SCAN_T + threadIdx.x;
+    L1 tot;
+    L1 ex = tile_scan<L1>(i < n ? in[i] : 0u, tile_seed[blockIdx.x], sh, &tot, [](L1 a, L1 b) { return l1_compose(a, b); },
+                          [](L1 v, int d) { return (L1)__shfl_up(v, d, 64); });
+    if (i < n) out_state[i] = ex;
+}
 
-__global__ __launch_bounds__(SCAN_T) void k_scan_l2(const L2 *__restrict__ in, uint32_t n, Carry *carry, L2 *__restrict__ out_state, uint32_t km1) {
+__global__ __launch_bounds__(SCAN_T) void k_scan_l2_reduce(const L2 *__restrict__ in, uint32_t n, L2 *__restrict__ tile_tot, uint32_t km1) {
     __shared__ L2 sh[SCAN_T / 64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * SCAN_T + threadIdx.x;
+    L2 tot;
+    tile_scan<L2>(i < n ? in[i] : l2_identity(), l2_identity(), sh, &tot, [km1](const L2 &a, const L2 &b) { return l2_compose(a, b, km1); },
+                  [](const L2 &v, int d) { return shfl_up_l2(v, d); });
+    if (threadIdx.x == 0) tile_tot[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(SCAN_T) void k_scan_l2_tiles(L2 *__restrict__ tile_tot, uint32_t n_tiles, Carry *carry, uint32_t km1) {
+    __shared__ L2 sh[SCAN_T / 64];
     L2 run = carry->l2;
-    for (uint32_t t0 = 0; t0 < n; t0 += SCAN_T) {
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += SCAN_T) {
         const uint32_t i = t0 + threadIdx.x;
-        const L2 mine = i < n ? in[i] : l2_identity();
-        const L2 inc = wave_incl_scan_l2(mine, lane, km1);
-        if (lane == 63) sh[w] = inc;
-        __syncthreads();
-        L2 pre = run, tot = run;
-        for (int j = 0; j < SCAN_T / 64; j++) { if (j == w) pre = tot; tot = l2_compose(tot, sh[j], km1); }
-        const L2 up = shfl_up_l2(inc, 1);
-        if (i < n) out_state[i] = (lane == 0) ? pre : l2_compose(pre, up, km1);
+        L2 tot;
+        L2 ex = tile_scan<L2>(i < n_tiles ? tile_tot[i] : l2_identity(), run, sh, &tot,
+                              [km1](const L2 &a, const L2 &b) { return l2_compose(a, b, km1); }, [](const L2 &v, int d) { return shfl_up_l2(v, d); });
+        if (i < n_tiles) tile_tot[i] = ex;
         run = tot;
         __syncthreads();
     }
     if (threadIdx.x == 0) { carry->l2 = run; carry->n_recs = run.rec; }
+}
+__global__ __launch_bounds__(SCAN_T) void k_scan_l2_apply(const L2 *__restrict__ in, uint32_t n, const L2 *__restrict__ tile_seed,
+                                                          L2 *__restrict__ out_state, uint32_t km1) {
+    __shared__ L2 sh[SCAN_T / 64];
+    const uint32_t i = blockIdx.x * SCAN_T + threadIdx.x;
+    L2 tot;
+    L2 ex = tile_scan<L2>(i < n ? in[i] : l2_identity(), tile_seed[blockIdx.x], sh, &tot,
+                          [km1](const L2 &a, const L2 &b) { return l2_compose(a, b, km1); }, [](const L2 &v, int d) { return shfl_up_l2(v, d); });
+    if (i < n) out_state[i] = ex;
 }
 
 // ------------------------------------------------------------------ k-mer walk -----------------
@@ -222,15 +264,22 @@ __global__ __launch_bounds__(WG) void k_clamp32(uint32_t *__restrict__ t, uint64
 void launch_chunk_l1(const uint8_t *fasta, uint64_t n, L1 *chunk_l1, uint32_t n_chunks, hipStream_t s) {
     hipLaunchKernelGGL(k_chunk_l1, dim3(n_chunks), dim3(WG), 0, s, fasta, n, chunk_l1);
 }
-void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_scan_l1, dim3(1), dim3(SCAN_T), 0, s, in, n_chunks, carry, out);
+// tile_ws: scratch for ceil(n_chunks / 1024) summaries of the respective type
+void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, L1 *tile_ws, hipStream_t s) {
+    const uint32_t n_tiles = (n_chunks + SCAN_T - 1) / SCAN_T;
+    hipLaunchKernelGGL(k_scan_l1_reduce, dim3(n_tiles), dim3(SCAN_T), 0, s, in, n_chunks, tile_ws);
+    hipLaunchKernelGGL(k_scan_l1_tiles, dim3(1), dim3(SCAN_T), 0, s, tile_ws, n_tiles, carry);
+    hipLaunchKernelGGL(k_scan_l1_apply, dim3(n_tiles), dim3(SCAN_T), 0, s, in, n_chunks, (const L1 *)tile_ws, out);
 }
 void launch_chunk_l2(const uint8_t *fasta, uint64_t n, const L1 *st1, L2 *chunk_l2, LaneState *lane_state, uint32_t n_chunks, uint32_t k,
                      hipStream_t s) {
     hipLaunchKernelGGL(k_chunk_l2, dim3(n_chunks), dim3(WG), 0, s, fasta, n, st1, chunk_l2, lane_state, k - 1);
 }
-void launch_scan_l2(const L2 *in, uint32_t n_chunks, Carry *carry, L2 *out, uint32_t k, hipStream_t s) {
-    hipLaunchKernelGGL(k_scan_l2, dim3(1), dim3(SCAN_T), 0, s, in, n_chunks, carry, out, k - 1);
+void launch_scan_l2(const L2 *in, uint32_t n_chunks, Carry *carry, L2 *out, L2 *tile_ws, uint32_t k, hipStream_t s) {
+    const uint32_t n_tiles = (n_chunks + SCAN_T - 1) / SCAN_T;
+    hipLaunchKernelGGL(k_scan_l2_reduce, dim3(n_tiles), dim3(SCAN_T), 0, s, in, n_chunks, tile_ws, k - 1);
+    hipLaunchKernelGGL(k_scan_l2_tiles, dim3(1), dim3(SCAN_T), 0, s, tile_ws, n_tiles, carry, k - 1);
+    hipLaunchKernelGGL(k_scan_l2_apply, dim3(n_tiles), dim3(SCAN_T), 0, s, in, n_chunks, (const L2 *)tile_ws, out, k - 1);
 }
 void launch_count(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, uint32_t n_chunks,
                   uint32_t k, uint32_t *table32, DevRec *recs, uint64_t recs_cap, Carry *carry, hipStream_t s) {

@@ -22,6 +22,7 @@
 // record order (hence the result) is deterministic.  Saturation is exact: min(255, .) is applied
 // only when a bucket's counters leave LDS (indexer.py:239,262), and K6 folds the slice already in
 // HBM back in, so several feeds accumulate exactly like the reference's flushes.
+#include <cstddef>
 #include <cstdlib>
 #include "fasta_fsm.h"
 #include "kmer_walk.h"
@@ -263,13 +264,17 @@ __global__ __launch_bounds__(1024) void k_rows1_scan(const uint32_t *__restrict_
 // counts, records + digits parked in LDS in sorted order, then written as coalesced runs at
 // run[d] (this workgroup's running output offset for digit d).
 struct ScatterLds {
-    uint32_t rec[TILE];
-    uint16_t dig[TILE];
     uint32_t hist[512], off[512], run[512], gbase[512];
     uint32_t wsum[SC_T / 64];
+    uint32_t rec[TILE];
+    uint16_t dig[TILE];            // only when the digit does not fit beside the record (k = 17, level 1)
 };
+constexpr size_t SCATTER_LDS_NARROW = offsetof(ScatterLds, dig);   // 72 KiB: two workgroups per CU
+constexpr size_t SCATTER_LDS_WIDE = sizeof(ScatterLds);            // 104 KiB
 
-template <typename RIN>
+// WIDE = the digit is kept in its own LDS array; otherwise the record parked in LDS still carries its
+// digit (digit << shift | rest fits 32 bits) and is masked on the way out.
+template <typename RIN, bool WIDE>
 __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PER], const bool (&ok)[SC_PER], uint32_t n_tile,
                                              uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out) {
     uint32_t dg[SC_PER], rk[SC_PER];
@@ -304,18 +309,39 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
     for (int j = 0; j < SC_PER; j++)
         if (ok[j]) {
             uint32_t p = L.off[dg[j]] + rk[j];
-            L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask);
-            L.dig[p] = (uint16_t)dg[j];
+            if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)dg[j]; }
+            else L.rec[p] = (uint32_t)r[j];
         }
     __syncthreads();
+    if (out16) {
+        // 16-bit records: each thread takes pairs of neighbours in sorted order and writes them as one
+        // dword when they fall in the same run and the destination is even (the common case)
+        uint16_t *o16 = reinterpret_cast<uint16_t *>(out);
 #pragma unroll
-    for (int j = 0; j < SC_PER; j++) {
-        uint32_t p = threadIdx.x + j * SC_T;
-        if (p < n_tile) {
-            uint32_t d = L.dig[p];
-            uint32_t dst = L.gbase[d] + (p - L.off[d]);
-            if (out16) reinterpret_cast<uint16_t *>(out)[dst] = (uint16_t)L.rec[p];
-            else reinterpret_cast<uint32_t *>(out)[dst] = L.rec[p];
+        for (int j = 0; j < SC_PER / 2; j++) {
+            const uint32_t p = 2u * (threadIdx.x + j * SC_T);
+            if (p < n_tile) {
+                const uint32_t r0 = L.rec[p], r1 = p + 1 < n_tile ? L.rec[p + 1] : 0u;
+                const uint32_t d0 = WIDE ? L.dig[p] : (r0 >> shift) & (B - 1u);
+                const uint32_t d1 = p + 1 < n_tile ? (WIDE ? (uint32_t)L.dig[p + 1] : (r1 >> shift) & (B - 1u)) : ~0u;
+                const uint32_t dst0 = L.gbase[d0] + (p - L.off[d0]);
+                if (d0 == d1 && (dst0 & 1u) == 0u) {
+                    *reinterpret_cast<uint32_t *>(o16 + dst0) = (r0 & low_mask) | ((r1 & low_mask) << 16);
+                } else {
+                    o16[dst0] = (uint16_t)(r0 & low_mask);
+                    if (p + 1 < n_tile) o16[L.gbase[d1] + (p + 1 - L.off[d1])] = (uint16_t)(r1 & low_mask);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SC_PER; j++) {
+            const uint32_t p = threadIdx.x + j * SC_T;
+            if (p < n_tile) {
+                const uint32_t rr = L.rec[p];
+                const uint32_t d = WIDE ? L.dig[p] : (rr >> shift) & (B - 1u);
+                reinterpret_cast<uint32_t *>(out)[L.gbase[d] + (p - L.off[d])] = rr & low_mask;
+            }
         }
     }
     __syncthreads();
@@ -355,7 +381,7 @@ __global__ __launch_bounds__(SC_T) void k_scatter1(const REC0 *__restrict__ flat
                 r[j] = src[s * SUB + (i - pre)];
             }
         }
-        scatter_tile<REC0>(L, r, ok, n_tile, shift, B, low_mask, out16, out);
+        scatter_tile<REC0, sizeof(REC0) == 8>(L, r, ok, n_tile, shift, B, low_mask, out16, out);
     }
 }
 
@@ -431,17 +457,22 @@ __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ 
     __syncthreads();
     if (threadIdx.x < B) L.run[threadIdx.x] = final_start[(uint64_t)b * B + threadIdx.x] + rowoff[(uint64_t)blockIdx.x * B + threadIdx.x];
     __syncthreads();
-    for (uint32_t t0 = lo; t0 < hi; t0 += TILE) {
-        const uint32_t n_tile = min((uint32_t)TILE, hi - t0);
+    // 16-byte aligned windows of TILE records over [lo, hi); the first / last window are partly masked
+    for (uint32_t win = lo & ~3u; win < hi; win += TILE) {
+        const uint32_t v_lo = max(lo, win), v_hi = min(hi, win + (uint32_t)TILE);
+        const uint32_t n_tile = v_hi - v_lo;
         uint32_t r[SC_PER];
         bool ok[SC_PER];
 #pragma unroll
-        for (int j = 0; j < SC_PER; j++) {
-            uint32_t i = threadIdx.x + j * SC_T;
-            ok[j] = i < n_tile;
-            r[j] = ok[j] ? in[t0 + i] : 0u;
+        for (int j = 0; j < SC_PER / 4; j++) {
+            const uint32_t i = win + (threadIdx.x + j * SC_T) * 4u;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i < v_hi) v = *reinterpret_cast<const uint4 *>(in + i);
+            const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) { ok[j * 4 + e] = i + e >= v_lo && i + e < v_hi; r[j * 4 + e] = q[e]; }
         }
-        scatter_tile<uint32_t>(L, r, ok, n_tile, shift, B, low_mask, true, out);
+        scatter_tile<uint32_t, false>(L, r, ok, n_tile, shift, B, low_mask, true, out);
     }
 }
 
@@ -634,9 +665,9 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     uint32_t *final_start = (uint32_t *)(ws + lay.final_start), *hist2 = (uint32_t *)(ws + lay.hist2), *rowoff2 = (uint32_t *)(ws + lay.rowoff2);
     void *flat = ws + lay.flat, *out1 = ws + lay.out1, *out2 = ws + lay.out2;
     unsigned long long *side = (unsigned long long *)(ws + lay.side), *side_n = (unsigned long long *)(ws + lay.side_n);
-    hipFuncSetAttribute((const void *)k_scatter1<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds));
-    hipFuncSetAttribute((const void *)k_scatter1<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds));
-    hipFuncSetAttribute((const void *)k_scatter2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ScatterLds));
+    hipFuncSetAttribute((const void *)k_scatter1<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
+    hipFuncSetAttribute((const void *)k_scatter1<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_WIDE);
+    hipFuncSetAttribute((const void *)k_scatter2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_bucket_count, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (hipMemsetAsync(side_n, 0, 8, s) != hipSuccess) return -2;
     if (pl.k <= 15) {
@@ -653,16 +684,16 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     }
     hipLaunchKernelGGL(k_rows1_scan, dim3(1), dim3(1024), 0, s, hist1, rowoff1, pl, bucket_base, wg2_start, final_start);
     if (pl.k <= 15)
-        hipLaunchKernelGGL(k_scatter1<uint32_t>, dim3(pl.n_wg0), dim3(SC_T), sizeof(ScatterLds), s, (const uint32_t *)flat, cnt, rowoff1,
+        hipLaunchKernelGGL(k_scatter1<uint32_t>, dim3(pl.n_wg0), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)flat, cnt, rowoff1,
                            bucket_base, pl, out1);
     else
-        hipLaunchKernelGGL(k_scatter1<uint64_t>, dim3(pl.n_wg0), dim3(SC_T), sizeof(ScatterLds), s, (const uint64_t *)flat, cnt, rowoff1,
+        hipLaunchKernelGGL(k_scatter1<uint64_t>, dim3(pl.n_wg0), dim3(SC_T), SCATTER_LDS_WIDE, s, (const uint64_t *)flat, cnt, rowoff1,
                            bucket_base, pl, out1);
     const uint16_t *final_recs = (const uint16_t *)out1;
     if (pl.b2) {
         hipLaunchKernelGGL(k_count2, dim3(pl.n_wg2_max), dim3(WG), 0, s, (const uint32_t *)out1, wg2_start, bucket_base, pl, hist2);
         hipLaunchKernelGGL(k_rows2_scan, dim3(pl.B1), dim3(512), 0, s, hist2, rowoff2, wg2_start, bucket_base, pl, final_start);
-        hipLaunchKernelGGL(k_scatter2, dim3(pl.n_wg2_max), dim3(SC_T), sizeof(ScatterLds), s, (const uint32_t *)out1, wg2_start,
+        hipLaunchKernelGGL(k_scatter2, dim3(pl.n_wg2_max), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
                            bucket_base, rowoff2, final_start, pl, out2);
         final_recs = (const uint16_t *)out2;
     }

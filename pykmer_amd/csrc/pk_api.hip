@@ -94,6 +94,8 @@ struct pk_indexer {
     L1 *c_l1 = nullptr, *c_l1s = nullptr;
     L2 *c_l2 = nullptr, *c_l2s = nullptr;
     LaneState *lane_state = nullptr;   // per 64-byte piece: start state relative to its chunk
+    L1 *t_l1 = nullptr;                // scan scratch: one summary per 1024 chunks
+    L2 *t_l2 = nullptr;
     uint32_t chunk_cap = 0;
     uint8_t *staging = nullptr;      // device copy of host-fed bytes
     uint64_t staging_cap = 0;
@@ -136,7 +138,7 @@ extern "C" void pk_indexer_destroy(pk_indexer *ix) {
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
     hipFree(ix->table32); hipFree(ix->table8); hipFree(ix->carry); hipFree(ix->hist); hipFree(ix->recs);
-    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state); hipFree(ix->staging); hipFree(ix->ws);
+    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state); hipFree(ix->t_l1); hipFree(ix->t_l2); hipFree(ix->staging); hipFree(ix->ws);
     for (auto &e : ix->ev) if (e) hipEventDestroy(e);
     if (ix->stream) hipStreamDestroy(ix->stream);
     delete ix;
@@ -179,13 +181,16 @@ extern "C" int pk_indexer_reset(pk_indexer *ix) {
 
 static int ensure_chunks(pk_indexer *ix, uint32_t n_chunks) {
     if (n_chunks <= ix->chunk_cap) return PK_OK;
-    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state);
-    ix->c_l1 = ix->c_l1s = nullptr; ix->c_l2 = ix->c_l2s = nullptr; ix->lane_state = nullptr; ix->chunk_cap = 0;
+    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state); hipFree(ix->t_l1); hipFree(ix->t_l2);
+    ix->c_l1 = ix->c_l1s = nullptr; ix->c_l2 = ix->c_l2s = nullptr; ix->lane_state = nullptr; ix->t_l1 = nullptr; ix->t_l2 = nullptr;
+    ix->chunk_cap = 0;
     HIPCHK(hipMalloc(&ix->c_l1, n_chunks * sizeof(L1)));
     HIPCHK(hipMalloc(&ix->c_l1s, n_chunks * sizeof(L1)));
     HIPCHK(hipMalloc(&ix->c_l2, n_chunks * sizeof(L2)));
     HIPCHK(hipMalloc(&ix->c_l2s, n_chunks * sizeof(L2)));
     HIPCHK(hipMalloc(&ix->lane_state, (size_t)n_chunks * WG * sizeof(LaneState)));
+    HIPCHK(hipMalloc(&ix->t_l1, ((size_t)n_chunks / 1024 + 1) * sizeof(L1)));
+    HIPCHK(hipMalloc(&ix->t_l2, ((size_t)n_chunks / 1024 + 1) * sizeof(L2)));
     ix->chunk_cap = n_chunks;
     return PK_OK;
 }
@@ -223,9 +228,9 @@ extern "C" int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uin
     const uint8_t *f = (const uint8_t *)dev_fasta;
     HIPCHK(hipEventRecord(ix->ev[0], ix->stream));
     launch_chunk_l1(f, n_bytes, ix->c_l1, n_chunks, ix->stream);
-    launch_scan_l1(ix->c_l1, n_chunks, ix->carry, ix->c_l1s, ix->stream);
+    launch_scan_l1(ix->c_l1, n_chunks, ix->carry, ix->c_l1s, ix->t_l1, ix->stream);
     launch_chunk_l2(f, n_bytes, ix->c_l1s, ix->c_l2, ix->lane_state, n_chunks, (uint32_t)ix->k, ix->stream);
-    launch_scan_l2(ix->c_l2, n_chunks, ix->carry, ix->c_l2s, (uint32_t)ix->k, ix->stream);
+    launch_scan_l2(ix->c_l2, n_chunks, ix->carry, ix->c_l2s, ix->t_l2, (uint32_t)ix->k, ix->stream);
     HIPCHK(hipEventRecord(ix->ev[1], ix->stream));
     uint64_t n_recs = 0;
     HIPCHK(hipMemcpyAsync(&n_recs, &ix->carry->n_recs, sizeof n_recs, hipMemcpyDeviceToHost, ix->stream));

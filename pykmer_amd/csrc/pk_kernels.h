@@ -26,10 +26,10 @@ struct Carry {
 };
 
 void launch_chunk_l1(const uint8_t *fasta, uint64_t n, L1 *chunk_l1, uint32_t n_chunks, hipStream_t s);
-void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, hipStream_t s);
+void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, L1 *tile_ws, hipStream_t s);
 void launch_chunk_l2(const uint8_t *fasta, uint64_t n, const L1 *st1, L2 *chunk_l2, LaneState *lane_state, uint32_t n_chunks, uint32_t k,
                      hipStream_t s);
-void launch_scan_l2(const L2 *in, uint32_t n_chunks, Carry *carry, L2 *out, uint32_t k, hipStream_t s);
+void launch_scan_l2(const L2 *in, uint32_t n_chunks, Carry *carry, L2 *out, L2 *tile_ws, uint32_t k, hipStream_t s);
 void launch_count(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, uint32_t n_chunks,
                   uint32_t k, uint32_t *table32, DevRec *recs, uint64_t recs_cap, Carry *carry, hipStream_t s);
 void launch_finalize(const uint32_t *table32, uint8_t *table8, uint64_t n, unsigned long long *hist, hipStream_t s);
