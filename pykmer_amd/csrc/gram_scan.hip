@@ -148,16 +148,31 @@ __global__ __launch_bounds__(512) void k_gram_blk(const uint8_t *const *__restri
     const int items = NB * BLK * TILE_WORDS;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t w0 = tile * TILE_WORDS;
-        // phase 1: every (table, word) of the tile -> mask in LDS; consecutive lanes, consecutive words
-        for (int q = threadIdx.x; q < items; q += nthreads) {
-            int t = q / TILE_WORDS, w = q % TILE_WORDS;
-            uint32_t m = 0;
-            if (t < N && w0 + w < n_words) {
-                uint4 a, b;
-                load_word(tables[t], w0 + w, n, a, b);
-                m = mask32<FAST>(a, b, vp);
+        // phase 1: every (table, word) of the tile -> mask in LDS; consecutive lanes, consecutive words.
+        // Ping-pong register sets keep 4 x 16-byte loads per thread in flight continuously: set B is
+        // requested before set A is turned into masks and vice versa (the waits the compiler inserts are
+        // counted, so only the older set is waited for).  The table index is wave-uniform (256 words per
+        // table row), so the table pointer comes from a scalar load.
+        auto fetch = [&](int q, uint4 &a, uint4 &b) -> bool {
+            const int t = __builtin_amdgcn_readfirstlane(q / TILE_WORDS), w = q % TILE_WORDS;
+            const bool live = q < items && t < N && w0 + w < n_words;
+            a = make_uint4(0, 0, 0, 0); b = a;
+            if (live) load_word(tables[t], w0 + w, n, a, b);
+            return live;
+        };
+        {
+            const int step = 2 * nthreads;
+            uint4 a0, b0, a1, b1, c0, d0, c1, d1;
+            int q = threadIdx.x;
+            bool la0 = fetch(q, a0, b0), la1 = fetch(q + nthreads, a1, b1);
+            for (; q < items; q += 2 * step) {
+                const bool lc0 = fetch(q + step, c0, d0), lc1 = fetch(q + step + nthreads, c1, d1);
+                if (q < items) masks[q] = la0 ? mask32<FAST>(a0, b0, vp) : 0u;
+                if (q + nthreads < items) masks[q + nthreads] = la1 ? mask32<FAST>(a1, b1, vp) : 0u;
+                la0 = fetch(q + 2 * step, a0, b0); la1 = fetch(q + 2 * step + nthreads, a1, b1);
+                if (q + step < items) masks[q + step] = lc0 ? mask32<FAST>(c0, d0, vp) : 0u;
+                if (q + step + nthreads < items) masks[q + step + nthreads] = lc1 ? mask32<FAST>(c1, d1, vp) : 0u;
             }
-            masks[q] = m;
         }
         __syncthreads();
         // phase 2: each wave tallies its 8x8 pair blocks over the tile's words
@@ -228,12 +243,12 @@ int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int m
         const int NB = (N + BLK - 1) / BLK;
         const size_t lds = (size_t)NB * BLK * TILE_WORDS * sizeof(uint32_t);
         uint64_t n_tiles = (n_words + TILE_WORDS - 1) / TILE_WORDS;
-        uint32_t grid = (uint32_t)(n_tiles < 512u ? n_tiles : 512u);
+        uint32_t grid = (uint32_t)(n_tiles < 1024u ? n_tiles : 1024u);
         PairBlocks pbs;
         pbs.n = 0;
         auto flush = [&]() {
             if (!pbs.n) return;
-            const int slots = pbs.n <= 16 ? 2 : 3;
+            const int slots = pbs.n <= 16 ? 2 : 3;         // 128 / 192 accumulators per lane
             const int waves = (pbs.n + slots - 1) / slots;
             if (lds > 64u * 1024u) {                       // opt in to more than 64 KiB of dynamic LDS
                 hipFuncSetAttribute((const void *)k_gram_blk<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
