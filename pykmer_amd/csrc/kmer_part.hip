@@ -482,17 +482,26 @@ __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ 
 // counter (<= 255 + 65024) can never carry into its neighbour.
 constexpr uint32_t K6_PIECE = 65024;   // multiple of 8
 
+// `fresh` = first feed after a reset: the table holds nothing yet (it is not even zeroed), so slices
+// are not read back and buckets without records are written as zeros.
 __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
-                                                       uint32_t fb_bits, uint8_t *__restrict__ table8) {
+                                                       uint32_t fb_bits, uint8_t *__restrict__ table8, uint32_t fresh) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);                  // 2^fb_bits / 2 dwords
     const uint32_t fb = blockIdx.x;
     const uint32_t start = final_start[fb], end = final_start[fb + 1];
-    if (start == end) return;                                            // slice untouched
     const uint32_t n_addr = 1u << fb_bits;
     uint8_t *slice = table8 + (uint64_t)fb * n_addr;
-    // fold in what the slice already holds (earlier feeds); slices are >= 16 bytes except at k = 1
-    if (n_addr >= 16) {
+    if (start == end) {
+        if (fresh) {                                                     // nothing counted here: the slice is all zero
+            if (n_addr >= 16) for (uint32_t g = threadIdx.x; g < n_addr / 16; g += SC_T) reinterpret_cast<uint4 *>(slice)[g] = make_uint4(0, 0, 0, 0);
+            else for (uint32_t a = threadIdx.x; a < n_addr; a += SC_T) slice[a] = 0;
+        }
+        return;                                                          // otherwise the slice stays as it is
+    }
+    if (fresh) {
+        for (uint32_t a = threadIdx.x; a < max(n_addr / 2, 1u); a += SC_T) cnt[a] = 0u;
+    } else if (n_addr >= 16) {                                           // fold in what the slice already holds (earlier feeds)
         for (uint32_t g = threadIdx.x; g < n_addr / 16; g += SC_T) {
             uint4 v = reinterpret_cast<const uint4 *>(slice)[g];
             uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -659,7 +668,7 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
 
 int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, const PartPlan &pl,
                        uint8_t *ws, const PartWorkspace &lay, uint8_t *table8, DevRec *recs, uint64_t recs_cap, Carry *carry,
-                       hipStream_t s, hipEvent_t ev_walk_end, hipEvent_t ev_part_end) {
+                       hipStream_t s, hipEvent_t ev_walk_end, hipEvent_t ev_part_end, bool fresh) {
     uint32_t *cnt = (uint32_t *)(ws + lay.cnt), *hist1 = (uint32_t *)(ws + lay.hist1), *rowoff1 = (uint32_t *)(ws + lay.rowoff1);
     uint32_t *bucket_base = (uint32_t *)(ws + lay.bucket_base), *wg2_start = (uint32_t *)(ws + lay.wg2_start);
     uint32_t *final_start = (uint32_t *)(ws + lay.final_start), *hist2 = (uint32_t *)(ws + lay.hist2), *rowoff2 = (uint32_t *)(ws + lay.rowoff2);
@@ -700,7 +709,7 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     if (ev_part_end) hipEventRecord(ev_part_end, s);
     const uint32_t nfb = pl.B1 * pl.B2;
     const size_t lds6 = ((size_t)1 << pl.fb_bits) * 2 < 64 ? 64 : ((size_t)1 << pl.fb_bits) * 2;
-    hipLaunchKernelGGL(k_bucket_count, dim3(nfb), dim3(SC_T), lds6, s, final_recs, final_start, pl.fb_bits, table8);
+    hipLaunchKernelGGL(k_bucket_count, dim3(nfb), dim3(SC_T), lds6, s, final_recs, final_start, pl.fb_bits, table8, fresh ? 1u : 0u);
     hipLaunchKernelGGL(k_apply_side, dim3(AS_WGS), dim3(WG), 0, s, side, side_n, lay.side_cap, table8);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -104,6 +104,7 @@ struct pk_indexer {
     hipEvent_t ev[12] = {};
     double t_scan = 0, t_count = 0, t_final = 0, t_zero = 0, t_part = 0, t_bucket = 0;
     int count_launches = 0;
+    bool table_fresh = true;         // partitioned mode: no feed has written the u8 table since the last reset
     bool direct = false;             // PK_COUNT_MODE=direct: version-1 table update (global atomics on u32 counters)
     uint8_t *ws = nullptr;           // partitioned mode workspace
     size_t ws_cap = 0;
@@ -113,7 +114,8 @@ static int ix_reset(pk_indexer *ix) {
     HIPCHK(hipSetDevice(ix->device));
     HIPCHK(hipEventRecord(ix->ev[6], ix->stream));
     if (ix->direct) HIPCHK(hipMemsetAsync(ix->table32, 0, ix->n * sizeof(uint32_t), ix->stream));
-    else HIPCHK(hipMemsetAsync(ix->table8, 0, std::max<uint64_t>(ix->n, 16), ix->stream));
+    // partitioned mode: the first feed writes every slice of the u8 table itself (k_bucket_count, fresh);
+    // the table is only zeroed here if nothing gets fed at all (see pk_indexer_finish)
     HIPCHK(hipEventRecord(ix->ev[7], ix->stream));
     Carry c;
     memset(&c, 0, sizeof c);
@@ -128,6 +130,7 @@ static int ix_reset(pk_indexer *ix) {
     ix->t_zero = ms * 1e-3;
     ix->bytes_fed = ix->since_clamp = ix->n_recs = 0;
     ix->finished = false;
+    ix->table_fresh = true;
     ix->t_scan = ix->t_count = ix->t_final = ix->t_part = ix->t_bucket = 0;
     ix->count_launches = 0;
     return PK_OK;
@@ -257,8 +260,9 @@ extern "C" int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uin
         }
         HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
         if (launch_partitioned(f, n_bytes, ix->bytes_fed, ix->lane_state, ix->c_l2s, pl, ix->ws, lay, ix->table8, ix->recs, ix->recs_cap,
-                               ix->carry, ix->stream, ix->ev[3], ix->ev[8]))
+                               ix->carry, ix->stream, ix->ev[3], ix->ev[8], ix->table_fresh))
             return fail(PK_ERR_HIP, "partition pipeline launch failed: %s", hipGetErrorString(hipGetLastError()));
+        ix->table_fresh = false;
         HIPCHK(hipEventRecord(ix->ev[9], ix->stream));
         HIPCHK(hipStreamSynchronize(ix->stream));
         HIPCHK(hipEventElapsedTime(&c, ix->ev[3], ix->ev[8]));
@@ -298,7 +302,13 @@ extern "C" int pk_indexer_finish(pk_indexer *ix, uint64_t *num_kmers_out, uint64
     if (!ix->finished) {
         HIPCHK(hipEventRecord(ix->ev[4], ix->stream));
         if (ix->direct) launch_finalize(ix->table32, ix->table8, ix->n, ix->hist, ix->stream);
-        else launch_hist8(ix->table8, ix->n, ix->hist, ix->stream);
+        else {
+            if (ix->table_fresh) {                           // nothing was fed: the table is all zero
+                HIPCHK(hipMemsetAsync(ix->table8, 0, std::max<uint64_t>(ix->n, 16), ix->stream));
+                ix->table_fresh = false;
+            }
+            launch_hist8(ix->table8, ix->n, ix->hist, ix->stream);
+        }
         HIPCHK(hipEventRecord(ix->ev[5], ix->stream));
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ix->stream));

@@ -55,7 +55,7 @@ PartPlan make_part_plan(uint32_t k, uint64_t n_bytes);
 size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace *lay);
 int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, const PartPlan &pl,
                        uint8_t *ws, const PartWorkspace &lay, uint8_t *table8, DevRec *recs, uint64_t recs_cap, Carry *carry,
-                       hipStream_t s, hipEvent_t ev_walk_end, hipEvent_t ev_part_end);
+                       hipStream_t s, hipEvent_t ev_walk_end, hipEvent_t ev_part_end, bool fresh);
 
 // gram_scan.hip
 // tables: device array of N device pointers, each n_slice bytes (16-byte aligned).  pair: device N*N u64,
