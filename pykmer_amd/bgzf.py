@@ -1,0 +1,154 @@
+"""BGZF (blocked gzip) reader / writer for `.kin.bgz` tables and `.fa.gz` inputs -- SURVEY.md 8f rows f1/f2.
+
+The reference compresses finished tables with the htslib CLI (`bgzip -i -I $F.bgz.gzi -l 9 -c $F > $F.bgz`,
+README.md:26, data/README.md:24) and reads them back through one single-threaded `gzip.open`
+(tools.py:294-305).  A BGZF file is a series of independent gzip members of <= 64 KiB each carrying
+their compressed size in a `BC` extra field (SAM spec 4.1), so both directions parallelise over
+blocks; zlib releases the GIL, so plain threads are enough.  The `.gzi` index is the layout
+gzireader.py:12-34 prints: u64 count, then (compressed_offset, uncompressed_offset) u64 pairs for
+every block but the first.
+
+Files that are gzip but not BGZF (what python's gzip module writes, and what the reference's own
+tests use as `.bgz`) are detected and handed to the sequential gzip reader.
+"""
+import gzip
+import os
+import struct
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+from typing import List, Tuple
+
+import numpy as np
+
+BLOCK_INPUT = 0xFF00                    # uncompressed bytes per block (htslib BGZF_BLOCK_SIZE)
+_HEADER = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00"
+EOF_BLOCK = _HEADER + struct.pack("<H", 27) + b"\x03\x00" + struct.pack("<II", 0, 0)
+DEFAULT_THREADS = max(1, min(16, os.cpu_count() or 1))
+
+
+def _deflate_block(data: bytes, level: int) -> bytes:
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    body = co.compress(data) + co.flush()
+    if len(body) + 26 > 0x10000:        # incompressible input: store it (level 0 always fits 0xFF00 bytes)
+        co = zlib.compressobj(0, zlib.DEFLATED, -15)
+        body = co.compress(data) + co.flush()
+    return _HEADER + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(data), len(data))
+
+
+def compress_file(src: str, dst: str = None, level: int = 9, threads: int = DEFAULT_THREADS, index: bool = True,
+                  batch_blocks: int = 512) -> Tuple[str, str]:
+    """`bgzip -i -I dst.gzi -l 9 -c src > dst`: writes dst (default src + '.bgz') via .tmp + rename and,
+    if `index`, dst + '.gzi'.  Returns (dst, gzi path or None)."""
+    dst = dst or src + ".bgz"
+    tmp = dst + ".tmp"
+    entries: List[Tuple[int, int]] = []
+    c_off = u_off = 0
+    with open(src, "rb") as fin, open(tmp, "wb") as fout, ThreadPoolExecutor(max_workers=threads) as pool:
+        while True:
+            chunk = fin.read(BLOCK_INPUT * batch_blocks)
+            if not chunk:
+                break
+            view = memoryview(chunk)
+            pieces = [view[i:i + BLOCK_INPUT] for i in range(0, len(chunk), BLOCK_INPUT)]
+            for piece, blk in zip(pieces, pool.map(lambda p: _deflate_block(bytes(p), level), pieces)):
+                if c_off:                                    # htslib lists every block except the first
+                    entries.append((c_off, u_off))
+                fout.write(blk)
+                c_off += len(blk)
+                u_off += len(piece)
+        fout.write(EOF_BLOCK)
+    os.replace(tmp, dst)
+    gzi = None
+    if index:
+        gzi = dst + ".gzi"
+        with open(gzi, "wb") as fh:
+            fh.write(struct.pack("<Q", len(entries)))
+            for c, u in entries:
+                fh.write(struct.pack("<QQ", c, u))
+    return dst, gzi
+
+
+def read_gzi(path: str) -> List[Tuple[int, int]]:
+    """gzireader.py:12-34."""
+    with open(path, "rb") as fh:
+        (n,) = struct.unpack("<Q", fh.read(8))
+        return [struct.unpack("<QQ", fh.read(16)) for _ in range(n)]
+
+
+def scan_blocks(buf) -> List[Tuple[int, int]]:
+    """[(offset, block_size)] of every BGZF block in a bytes-like, or [] if the data is not BGZF."""
+    blocks, pos, n = [], 0, len(buf)
+    while pos < n:
+        if n - pos < 18 or buf[pos:pos + 4] != b"\x1f\x8b\x08\x04":
+            return []
+        xlen = struct.unpack_from("<H", buf, pos + 10)[0]
+        x, end, bsize = pos + 12, pos + 12 + xlen, None
+        while x + 4 <= end:
+            si1, si2, slen = buf[x], buf[x + 1], struct.unpack_from("<H", buf, x + 2)[0]
+            if si1 == 66 and si2 == 67 and slen == 2:
+                bsize = struct.unpack_from("<H", buf, x + 4)[0] + 1
+            x += 4 + slen
+        if bsize is None or pos + bsize > n:
+            return []
+        blocks.append((pos, bsize))
+        pos += bsize
+    return blocks
+
+
+def _inflate_block(buf, off: int, size: int, out, out_off: int) -> None:
+    xlen = struct.unpack_from("<H", buf, off + 10)[0]
+    body = buf[off + 12 + xlen: off + size - 8]
+    crc, isize = struct.unpack_from("<II", buf, off + size - 8)
+    data = zlib.decompress(body, -15, isize) if isize else b""
+    if len(data) != isize or zlib.crc32(data) != crc:
+        raise OSError(f"BGZF block at {off}: CRC / size mismatch")
+    out[out_off: out_off + isize] = np.frombuffer(data, dtype=np.uint8)
+
+
+def decompress_file(path: str, expected_size: int = None, threads: int = DEFAULT_THREADS) -> np.ndarray:
+    """Whole file -> uint8 array.  BGZF blocks are inflated in parallel straight into the result; any
+    other gzip stream goes through gzip.open like tools.py:300-302."""
+    raw = np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, np.uint8)
+    buf = memoryview(raw)
+    blocks = scan_blocks(buf)
+    if not blocks:
+        with gzip.open(path, "rb") as fh:
+            data = np.frombuffer(fh.read(), dtype=np.uint8)
+    else:
+        sizes = [struct.unpack_from("<I", buf, off + size - 4)[0] for off, size in blocks]
+        offs = np.concatenate(([0], np.cumsum(sizes, dtype=np.int64)))
+        data = np.empty(int(offs[-1]), dtype=np.uint8)
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            list(pool.map(lambda i: _inflate_block(buf, blocks[i][0], blocks[i][1], data, int(offs[i])), range(len(blocks))))
+    if expected_size is not None and data.size != expected_size:
+        raise AssertionError(f"{path}: {data.size} bytes after inflating, expected {expected_size}")
+    return data
+
+
+def is_bgzf(path: str) -> bool:
+    with open(path, "rb") as fh:
+        head = fh.read(18)
+    return len(head) == 18 and head[:4] == b"\x1f\x8b\x08\x04" and head[12:14] == b"BC"
+
+
+def main(argv=None) -> None:
+    """`python -m pykmer_amd.bgzf file.kin` -> file.kin.bgz + file.kin.bgz.gzi (the README's bgzip step)."""
+    import argparse
+    ap = argparse.ArgumentParser(description="BGZF-compress a file the way `bgzip -i -l 9` does")
+    ap.add_argument("file")
+    ap.add_argument("-l", "--level", type=int, default=9)
+    ap.add_argument("-@", "--threads", type=int, default=DEFAULT_THREADS)
+    ap.add_argument("-d", "--decompress", action="store_true")
+    ap.add_argument("--keep", action="store_true", help="keep the input (the README recipe removes it)")
+    a = ap.parse_args(argv)
+    if a.decompress:
+        out = a.file[:-4] if a.file.endswith(".bgz") else a.file + ".out"
+        decompress_file(a.file, threads=a.threads).tofile(out)
+    else:
+        compress_file(a.file, level=a.level, threads=a.threads)
+        if not a.keep:
+            os.remove(a.file)
+
+
+if __name__ == "__main__":
+    main()

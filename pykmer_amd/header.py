@@ -322,9 +322,8 @@ class Header(HeaderVars):
         """The whole table as a host array (raw .kin, or python-gzip .kin.bgz as tools.py:300-302 reads it)."""
         path = index_file or self.index_file
         if path.endswith(".bgz"):
-            with gzip.open(path, "rb") as fh:
-                data = fh.read()
-            table = np.frombuffer(data, dtype=np.uint8)
+            from . import bgzf                                # BGZF blocks inflate in parallel; plain gzip falls back to gzip.open
+            table = bgzf.decompress_file(path)
         else:
             table = np.fromfile(path, dtype=np.uint8)
         assert table.size == self.data_size, f"{path}: {table.size} bytes, expected {self.data_size}"

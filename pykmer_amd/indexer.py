@@ -50,23 +50,38 @@ def _names_from_stream(input_file: str, records: np.ndarray) -> List[bytes]:
     return names
 
 
+def _pieces(input_file: str):
+    """The decompressed byte stream in FEED_BYTES pieces.  A BGZF-compressed FASTA (bgzip output) is
+    inflated block-parallel in one go when it is small enough to keep; everything else streams."""
+    if input_file.endswith((".gz", ".bgz")):
+        from . import bgzf
+        if bgzf.is_bgzf(input_file) and os.path.getsize(input_file) * 6 <= RESIDENT_LIMIT:
+            print(f"READING FASTA FROM BGZF {input_file}")
+            data = bgzf.decompress_file(input_file)
+            for off in range(0, data.size, FEED_BYTES):
+                yield data[off:off + FEED_BYTES].tobytes()
+            return
+    with _open_input(input_file) as fh:
+        while True:
+            piece = fh.read(FEED_BYTES)
+            if not piece:
+                return
+            yield piece
+
+
 def count_file(input_file: str, kmer_len: int, device: int = 0):
     """Streams one FASTA file through the GPU indexer.
 
     Returns (table u8[4^k] on the host, summary dict, all_records [(name, seq_len, n_valid)])."""
     kept, total = [], 0
     with _lib.Indexer(kmer_len, device=device) as ix:
-        with _open_input(input_file) as fh:
-            while True:
-                piece = fh.read(FEED_BYTES)
-                if not piece:
-                    break
-                ix.feed(piece)
-                total += len(piece)
-                if kept is not None:
-                    kept.append(piece)
-                    if total > RESIDENT_LIMIT:
-                        kept = None
+        for piece in _pieces(input_file):
+            ix.feed(piece)
+            total += len(piece)
+            if kept is not None:
+                kept.append(piece)
+                if total > RESIDENT_LIMIT:
+                    kept = None
         fin = ix.finish()
         recs = ix.records(fin["n_records"])
         table = ix.table_to_host()

@@ -1,0 +1,90 @@
+"""CPU: BGZF writer / parallel reader -- the README's `bgzip -i -I x.gzi -l 9` step and its inverse."""
+import gzip
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from pykmer_amd import bgzf
+
+
+def _table(n, seed, density=0.3):
+    rng = np.random.default_rng(seed)
+    t = rng.integers(1, 6, size=n, dtype=np.uint8)
+    t[rng.random(n) > density] = 0
+    return t
+
+
+@pytest.mark.parametrize("n", [0, 1, 65279, 65280, 65281, 4 ** 9, 1_000_003])
+def test_roundtrip_and_gzip_compatibility(tmp_path, n):
+    src = tmp_path / "t.07.kin"
+    data = _table(n, n)
+    data.tofile(src)
+    dst, gzi = bgzf.compress_file(str(src), threads=4)
+    assert dst == str(src) + ".bgz" and gzi == dst + ".gzi" and not os.path.exists(dst + ".tmp")
+    raw = open(dst, "rb").read()
+    assert raw.endswith(bgzf.EOF_BLOCK) and bgzf.is_bgzf(dst)
+    assert gzip.decompress(raw) == data.tobytes()                    # any gzip reader (the reference's gzip.open) accepts it
+    with gzip.open(dst, "rb") as fh:
+        assert fh.read() == data.tobytes()
+    back = bgzf.decompress_file(dst, expected_size=n, threads=4)
+    assert np.array_equal(back, data)
+    # block structure: every member carries BC, payload <= 0xFF00, sizes add up
+    blocks = bgzf.scan_blocks(memoryview(raw))
+    assert sum(s for _, s in blocks) == len(raw) and blocks[-1][1] == 28
+    isizes = [struct.unpack_from("<I", raw, off + size - 4)[0] for off, size in blocks]
+    assert max(isizes, default=0) <= 0xFF00 and sum(isizes) == n
+    # .gzi: u64 count + (compressed, uncompressed) pairs for every data block but the first (gzireader.py:12-34)
+    entries = bgzf.read_gzi(gzi)
+    data_blocks = blocks[:-1]
+    assert len(entries) == max(0, len(data_blocks) - 1)
+    u = 0
+    for (off, size), isz, want in zip(data_blocks[1:], isizes[1:], entries):
+        u += 0xFF00
+        assert want == (off, u)
+
+
+def test_incompressible_blocks_fit(tmp_path):
+    src = tmp_path / "r.bin"
+    data = np.random.default_rng(1).integers(0, 256, size=300_000, dtype=np.uint8)
+    data.tofile(src)
+    dst, _ = bgzf.compress_file(str(src), index=False, threads=2)
+    raw = open(dst, "rb").read()
+    assert all(size <= 0x10000 for _, size in bgzf.scan_blocks(memoryview(raw)))
+    assert np.array_equal(bgzf.decompress_file(dst), data)
+
+
+def test_plain_gzip_is_not_bgzf_but_still_read(tmp_path):
+    """What python's gzip writes (and the reference's tests call .bgz) has no BC field: sequential fallback."""
+    p = tmp_path / "x.07.kin.bgz"
+    data = _table(4 ** 7, 3)
+    with gzip.open(p, "wb") as fh:
+        fh.write(data.tobytes())
+    assert not bgzf.is_bgzf(str(p)) and bgzf.scan_blocks(memoryview(open(p, "rb").read())) == []
+    assert np.array_equal(bgzf.decompress_file(str(p), expected_size=4 ** 7), data)
+    with pytest.raises(AssertionError):
+        bgzf.decompress_file(str(p), expected_size=5)
+
+
+def test_corrupt_block_detected(tmp_path):
+    src = tmp_path / "c.bin"
+    _table(200_000, 5).tofile(src)
+    dst, _ = bgzf.compress_file(str(src), index=False)
+    raw = bytearray(open(dst, "rb").read())
+    raw[40] ^= 0xFF
+    open(dst, "wb").write(bytes(raw))
+    with pytest.raises((OSError, Exception)):
+        bgzf.decompress_file(dst)
+
+
+def test_header_reads_bgzf_table_and_cli(tmp_path, manifest):
+    from pykmer_amd.header import Header
+    from test_host_layer import _family_indexes
+    path = _family_indexes(tmp_path, manifest, n=1)[0]
+    want = np.fromfile(path, dtype=np.uint8)
+    bgzf.main([path])                                                # the README step: compress + remove the .kin
+    assert not os.path.exists(path) and os.path.exists(path + ".bgz") and os.path.exists(path + ".bgz.gzi")
+    h = Header(path + ".bgz", index_file=path + ".bgz")
+    assert h.index_file.endswith(".bgz") and np.array_equal(h.read_table(), want)
+    assert bytes(list(h)[:100]) == want[:100].tobytes()              # Header.__iter__ streams the same bytes (tools.py:527-533)
