@@ -42,7 +42,9 @@ def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "synth.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
-        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", src, "-o", _SO])
+        tmp = f"{_SO}.{os.getpid()}.tmp"               # several ranks may build at once: write aside, rename atomically
+        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", src, "-o", tmp])
+        os.replace(tmp, _SO)
     return _SO
 
 

@@ -28,6 +28,10 @@ def gpu():
     """The loaded C-ABI library on a box with a GPU; skips only when there is no GPU at all."""
     if not _gpu_present():
         pytest.skip("no GPU visible")
+    try:                 # one test uses torch for device tensors: bring it (and its HIP runtime) in before any GPU work
+        import torch     # noqa: F401
+    except ImportError:
+        pass
     from pykmer_amd import _lib
     _lib.load()          # raises ImportError if the extension was not built: loud failure
     return _lib
