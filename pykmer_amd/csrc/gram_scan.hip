@@ -63,7 +63,11 @@ __device__ __forceinline__ void load_word(const uint8_t *t, uint64_t w, uint64_t
     uint64_t off = w * 32u;
     if (off + 32u <= n) {
         const uint4 *p = reinterpret_cast<const uint4 *>(t + off);
-        a = p[0]; b = p[1];
+        // every byte is read exactly once: stream it past the caches (nontemporal)
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *q = reinterpret_cast<const u32x4 *>(p);
+        const u32x4 x = __builtin_nontemporal_load(q), y = __builtin_nontemporal_load(q + 1);
+        a = make_uint4(x.x, x.y, x.z, x.w); b = make_uint4(y.x, y.y, y.z, y.w);
     } else {
         uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (uint64_t i = off; i < n; i++) v[(i - off) >> 2] |= (uint32_t)t[i] << (8u * ((i - off) & 3u));
