@@ -334,13 +334,22 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
             }
         }
     } else {
+        // 32-bit records: neighbours in sorted order leave as one 8-byte store when they share a run
+        uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
 #pragma unroll
-        for (int j = 0; j < SC_PER; j++) {
-            const uint32_t p = threadIdx.x + j * SC_T;
+        for (int j = 0; j < SC_PER / 2; j++) {
+            const uint32_t p = 2u * (threadIdx.x + j * SC_T);
             if (p < n_tile) {
-                const uint32_t rr = L.rec[p];
-                const uint32_t d = WIDE ? L.dig[p] : (rr >> shift) & (B - 1u);
-                reinterpret_cast<uint32_t *>(out)[L.gbase[d] + (p - L.off[d])] = rr & low_mask;
+                const uint32_t r0 = L.rec[p], r1 = p + 1 < n_tile ? L.rec[p + 1] : 0u;
+                const uint32_t d0 = WIDE ? L.dig[p] : (r0 >> shift) & (B - 1u);
+                const uint32_t d1 = p + 1 < n_tile ? (WIDE ? (uint32_t)L.dig[p + 1] : (r1 >> shift) & (B - 1u)) : ~0u;
+                const uint32_t dst0 = L.gbase[d0] + (p - L.off[d0]);
+                if (d0 == d1 && (dst0 & 1u) == 0u) {
+                    *reinterpret_cast<uint2 *>(o32 + dst0) = make_uint2(r0 & low_mask, r1 & low_mask);
+                } else {
+                    o32[dst0] = r0 & low_mask;
+                    if (p + 1 < n_tile) o32[L.gbase[d1] + (p + 1 - L.off[d1])] = r1 & low_mask;
+                }
             }
         }
     }

@@ -170,3 +170,45 @@ def test_rejects_bad_k(gpu):
             gpu.count_fasta(b">a\nACGT\n", k)
     with pytest.raises(ValueError):
         gpu.count_fasta(b">a\nACGT\n", 19)                    # beyond the device path (256 GiB table)
+
+
+def test_structure_across_chunk_boundaries(gpu):
+    """Headers, CR/LF pairs, blank runs and tandem repeats placed right on the 64-byte piece and 16 KiB
+    chunk seams of the kernels, a header longer than a chunk, and many tiny records."""
+    rng = np.random.default_rng(77)
+
+    def seq(n):
+        return bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=n))
+
+    parts = [b">first\n"]
+    pos = len(parts[0])
+    for target in (64, 128, 16384, 16384 + 64, 2 * 16384, 3 * 16384 - 1, 3 * 16384 + 1, 5 * 16384):
+        for delta in (-2, -1, 0, 1, 2):
+            want = target * (1 + len(parts) // 7) + delta           # keep moving forward
+            if want <= pos + 8:
+                continue
+            body = seq(want - pos - 1) + b"\n"
+            parts.append(body); pos += len(body)
+            hdr = b">rec_at_%d extra words\r\n" % pos                # the '>' lands on / next to the seam
+            parts.append(hdr); pos += len(hdr)
+    long_header = b">" + b"H" * 40000 + b" tail \n"                  # header text spanning three chunks
+    parts.append(seq(100) + b"\n" + long_header + seq(5000) + b"\n")
+    parts.append(b">blanks\n" + seq(30) + b"   \t  " * 3000 + seq(30) + b"\n" + seq(20) + b" " * 20000 + b"\n" + seq(40) + b"\n")
+    parts.append(b">tandem\n" + b"A" * 70000 + b"\n" + b"AT" * 20000 + b"\n" + b"AAG" * 9000 + b"\n" + b"ACGT" * 5000 + b"\n")
+    parts.append(b"".join(b">t%d\nACGTTGCA%s\n" % (i, b"ACGT"[i % 4:i % 4 + 1] * (i % 9)) for i in range(5000)))
+    parts.append(b">crlf\r\n" + b"\r\n".join(seq(70) for _ in range(600)) + b"\r\n>last_no_newline\n" + seq(333))
+    data = b"".join(parts)
+    assert len(data) > 10 * 16384
+    for k in (5, 15):
+        _check_against_oracle(gpu, data, k)
+    # the same bytes through the streaming interface with cuts on and around the seams
+    want = oracle.count_fasta(data, 11)
+    cuts = sorted(set([0, len(data)] + [c for b in (64, 16384, 40000, 65536) for c in (b - 1, b, b + 1, 3 * b, 3 * b + 1) if c < len(data)]))
+    with gpu.Indexer(11) as ix:
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ix.feed(data[a:b])
+        fin = ix.finish()
+        recs = ix.records(fin["n_records"])
+        assert fin["num_kmers"] == want["num_kmers"] and np.array_equal(ix.table_to_host(), want["table"])
+        for f in ("name_off", "name_len", "seq_len", "n_valid_kmers"):
+            assert np.array_equal(recs[f], want["records"][f]), f
