@@ -51,6 +51,8 @@ int pk_dev_download(void *host_dst, const void *dev_src, uint64_t n_bytes, int d
 
 /* ---- indexer: replaces gen_kmers + canonical min + process_kmers (indexer.py:130-160, 341, 162-297)
  * and the parser that feeds them (indexer.py:45-99).  k must be odd, 1 <= k <= 17 (tools.py:165-167).
+ * Environment: PK_COUNT_MODE=direct selects the version-1 table update (one global atomic per k-mer on
+ * u32 counters) instead of the default partitioned one; results are identical.
  *
  * fasta       uncompressed FASTA text (what gzip.open(...,'rt') would hand the reference)
  * table_out   4^k bytes (host); receives table[a] = min(255, #canonical k-mers with value a): the
@@ -69,10 +71,10 @@ int pk_indexer_create(pk_indexer **out, int k, int device);
 int pk_indexer_reset(pk_indexer *ix);                       /* zero the table, forget parser state  */
 /* Feed the next n_bytes of the FASTA text.  Chunks may split lines, records and k-mers anywhere.   */
 int pk_indexer_feed(pk_indexer *ix, const uint8_t *host_fasta, uint64_t n_bytes);
-/* Same, but the bytes already sit in device memory on the indexer's device (16-byte aligned).
- * Work is enqueued on the indexer's stream; the call returns once the chunk's record count is known. */
+/* Same, but the bytes already sit in device memory on the indexer's device (16-byte aligned, < 4 GiB per
+ * call).  Work runs on the indexer's own stream; the call returns when the feed has been counted. */
 int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uint64_t n_bytes);
-/* Close the last record, clamp the table to u8 and build the 256-bin histogram, all in HBM.        */
+/* Close the last record and build the 256-bin value histogram of the u8 table, all in HBM.         */
 int pk_indexer_finish(pk_indexer *ix, uint64_t *num_kmers_out, uint64_t *total_bp_out,
                       uint64_t hist256_out[256], uint64_t *n_recs_out);
 int pk_indexer_records(pk_indexer *ix, pk_record *recs_out, uint64_t recs_cap);

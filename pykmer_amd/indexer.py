@@ -14,7 +14,6 @@ import numpy as np
 from . import _lib
 from .header import Header
 
-DEBUG = False
 FEED_BYTES = 1 << 30            # host -> device staging granularity
 RESIDENT_LIMIT = 16 << 30       # inputs up to this size (decompressed) are kept in host memory for the header names
 
