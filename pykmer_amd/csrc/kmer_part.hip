@@ -120,7 +120,7 @@ __device__ __forceinline__ void hot_flush(HotTable &H, unsigned long long *side,
 }
 
 // ------------------------------------------------------------------ K0: walk -> flat records ----
-template <typename KT, typename REC0>
+template <typename KT, typename REC0, bool DBG>
 __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
                                                   const LaneState *__restrict__ lane_state, const L2 *__restrict__ chunk_l2_state,
                                                   PartPlan pl, REC0 *__restrict__ flat, uint32_t *__restrict__ cnt,
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
         REC0 *region = flat + ((uint64_t)c * (WG / 64) + wave) * SUB;
         uint32_t wcount = 0;                               // wave-uniform
         // wave-uniform call: ballot-compact this step's records into the wave's region (coalesced store)
-        const uint32_t dbg = pl.dbg;
+        const uint32_t dbg = DBG ? pl.dbg : 0u;          // ablation bits exist only in the diagnostic instantiation
         auto wave_emit = [&](bool e, KT a) {
             unsigned long long m = __ballot(e);
             if (e) {
@@ -174,14 +174,22 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
         // ends.  Either route counts each k-mer exactly once.
         KT a1 = ~(KT)0, a2 = ~(KT)0, a3 = ~(KT)0;
         uint32_t n1 = 0, n2 = 0, n3 = 0;
-        auto route = [&](bool has, KT canon) {
-            const bool m1 = has && canon == a1, m2 = has && canon == a2, m3 = has && canon == a3;
-            const bool miss = has && !(m1 || m2 || m3);
-            n1 += m1 ? 1u : 0u; n2 += (m2 && !m1) ? 1u : 0u; n3 += (m3 && !m1 && !m2) ? 1u : 0u;
-            const uint32_t ev_n = miss ? n3 : 0u;
+        // written with 0/1 integers rather than bools: every compare is consumed at once, which keeps the
+        // number of live wave masks (SGPR pairs) in this loop small
+        auto route = [&](bool has_b, KT canon) {
+            const uint32_t has = has_b ? 1u : 0u;
+            const uint32_t m1 = has & (canon == a1 ? 1u : 0u);
+            const uint32_t m2 = has & (canon == a2 ? 1u : 0u) & (m1 ^ 1u);
+            const uint32_t m3 = has & (canon == a3 ? 1u : 0u) & ((m1 | m2) ^ 1u);
+            const uint32_t miss = has & ((m1 | m2 | m3) ^ 1u);
+            n1 += m1; n2 += m2; n3 += m3;
+            const bool missb = miss != 0u;
+            const uint32_t ev_n = missb ? n3 : 0u;
             const KT ev_a = a3;
-            if (miss) { a3 = a2; n3 = n2; a2 = a1; n2 = n1; a1 = canon; n1 = 0u; }
-            wave_emit((dbg & 1u) ? has : miss, canon);
+            a3 = missb ? a2 : a3; n3 = missb ? n2 : n3;
+            a2 = missb ? a1 : a2; n2 = missb ? n1 : n2;
+            a1 = missb ? canon : a1; n1 = missb ? 0u : n1;
+            wave_emit((dbg & 1u) ? has_b : missb, canon);
             if (__ballot(ev_n != 0u)) hot_insert_wave(&hot, (unsigned long long)ev_a, ev_n, side, side_n, side_cap);
         };
         if (dbg & 8u) {
@@ -688,15 +696,18 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     hipFuncSetAttribute((const void *)k_scatter2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_bucket_count, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (hipMemsetAsync(side_n, 0, 8, s) != hipSuccess) return -2;
-    if (pl.k <= 15) {
-        hipLaunchKernelGGL((k_walk_flat<uint32_t, uint32_t>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, pl,
+    if (pl.dbg && pl.k <= 15) {                              // diagnostic build of the walk (PK_DEBUG_WALK), timing only
+        hipLaunchKernelGGL((k_walk_flat<uint32_t, uint32_t, true>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, pl,
+                           (uint32_t *)flat, cnt, hist1, recs, recs_cap, carry, side, side_n, lay.side_cap);
+    } else if (pl.k <= 15) {
+        hipLaunchKernelGGL((k_walk_flat<uint32_t, uint32_t, false>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, pl,
                            (uint32_t *)flat, cnt, hist1, recs, recs_cap, carry, side, side_n, lay.side_cap);
     } else {
-        hipLaunchKernelGGL((k_walk_flat<uint64_t, uint64_t>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, pl,
+        hipLaunchKernelGGL((k_walk_flat<uint64_t, uint64_t, false>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, pl,
                            (uint64_t *)flat, cnt, hist1, recs, recs_cap, carry, side, side_n, lay.side_cap);
     }
     if (ev_walk_end) hipEventRecord(ev_walk_end, s);
-    if (pl.dbg) {                                            // ablation run: time the walk kernel only, results are garbage
+    if (pl.dbg && pl.k <= 15) {                              // ablation run: time the walk kernel only, results are garbage
         if (ev_part_end) hipEventRecord(ev_part_end, s);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }

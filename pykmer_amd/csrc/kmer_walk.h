@@ -112,7 +112,7 @@ struct Walker {
 
     // A whole CLEAN piece (sequence characters and line terminators only, no pending blanks, not
     // inside a header): the line/record machinery drops out and the loop is kept deliberately lean --
-    // 32-bit counters, integer flags, 4 bytes per iteration with constant shifts.  `sink(has, canon)`
+    // 32-bit counters, integer flags, 16 bytes per iteration with constant shifts.  `sink(has, canon)`
     // is called once per byte slot in wave-uniform control flow.
     template <class Sink>
     __device__ __forceinline__ void walk_clean(const uint8_t *lds, uint32_t nb, Sink &&sink) {
@@ -120,14 +120,18 @@ struct Walker {
         KT f = fwd, r = rev;
         uint32_t rn = run, n_seq = 0, n_kmer = 0;
         const uint32_t kk = k, live = rec != 0 ? 1u : 0u;
-        const uint32_t *words = reinterpret_cast<const uint32_t *>(mine);
+        // 16 bytes per ds_read_b128, fetched one iteration ahead; the 16 byte steps are unrolled with
+        // constant shifts (a rolled byte loop made the compiler issue one LDS read + full wait per byte)
+        uint4 nxt = mine[0];
 #pragma unroll 1
-        for (uint32_t q = 0; q < (uint32_t)PIECE / 4u; q++) {            // one dword per iteration: small code, constant shifts
-            const uint32_t wq = words[q];
-#pragma unroll
-            for (uint32_t j = 0; j < 4u; j++) {
-                uint32_t c = (wq >> (8u * j)) & 0xffu;
-                c = (q * 4u + j < nb) ? c : 10u;                         // past the end: behaves like a terminator
+        for (uint32_t q = 0; q < (uint32_t)PIECE / 16u; q++) {
+            const uint4 cur = nxt;
+            if (q + 1u < (uint32_t)PIECE / 16u) nxt = mine[q + 1u];
+            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll 16
+            for (uint32_t j = 0; j < 16u; j++) {
+                uint32_t c = (w[j >> 2] >> (8u * (j & 3u))) & 0xffu;
+                c = (q * 16u + j < nb) ? c : 10u;                        // past the end: behaves like a terminator
                 const uint32_t seq = (c != 10u && c != 13u) ? 1u : 0u;
                 const uint32_t b = (c >> 1) & 3u, code = b ^ (b >> 1);
                 const uint32_t valid = (c >> 6) == 1u ? ((0x0010008Au >> (c & 31u)) & 1u) : 0u;

@@ -7,7 +7,7 @@ process_kmers (indexer.py:45-297) happens in HBM behind pk_indexer_* (include/py
 import gzip
 import os
 import sys
-from typing import List, Tuple, Union
+from typing import List, Union
 
 import numpy as np
 

@@ -1,5 +1,4 @@
 """CPU: .kma -> Jaccard distance -> neighbour-joining tree."""
-import json
 import re
 
 import numpy as np

@@ -9,8 +9,6 @@ import sys
 import numpy as np
 import pytest
 
-import inputs
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

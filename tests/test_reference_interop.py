@@ -6,10 +6,7 @@ import os
 import sys
 import types
 
-import numpy as np
 import pytest
-
-import inputs
 
 REF = "/root/reference"
 pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "tools.py")), reason="reference not present")

@@ -1,6 +1,6 @@
-import os, sys, time, json
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch, synth
+import torch, synth
 from pykmer_amd import _lib
 fasta, bp = synth.c2(800_000_000, seed=2)
 n = int(fasta.size)
