@@ -11,6 +11,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The shared library is a build artefact (git-ignored): on a fresh checkout build it once, the way
+    # __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU).  If hipcc is absent the
+    # tests that need the library fail loudly with the ImportError from pykmer_amd._lib.load().
+    import shutil
+    from pykmer_amd import _lib, build as hip_build
+    if not os.path.exists(_lib.LIB_PATH) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        hip_build.build()
 
 
 def _gpu_present() -> bool:
