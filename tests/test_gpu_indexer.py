@@ -212,3 +212,24 @@ def test_structure_across_chunk_boundaries(gpu):
         assert fin["num_kmers"] == want["num_kmers"] and np.array_equal(ix.table_to_host(), want["table"])
         for f in ("name_off", "name_len", "seq_len", "n_valid_kmers"):
             assert np.array_equal(recs[f], want["records"][f]), f
+
+
+def test_many_distinct_tandem_repeats(gpu):
+    """Thousands of short tandem runs with different motifs: overflows the per-workgroup hot-key table
+    (direct side-list appends, mid-kernel flushes) and the re-aggregation table of k_apply_side."""
+    rng = np.random.default_rng(2024)
+    parts = [b">short_tandems\n"]
+    line = []
+    for _ in range(60000):
+        period = int(rng.integers(1, 4))
+        motif = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=period))
+        run = motif * int(rng.integers(12, 30))
+        spacer = bytes(b"ACGT"[i] for i in rng.integers(0, 4, size=int(rng.integers(0, 6))))
+        line.append(run + spacer)
+        if len(line) == 3:
+            parts.append(b"".join(line) + b"\n")
+            line = []
+    data = b"".join(parts)
+    assert len(data) > 2_000_000
+    for k in (9, 15):
+        _check_against_oracle(gpu, data, k)
