@@ -53,6 +53,8 @@ def build_parser() -> argparse.ArgumentParser:
     parser.add_argument("--block-size", type=int, default=DEFAULT_BLOCK_SIZE, nargs="?", help=f"Block size [{DEFAULT_BLOCK_SIZE}]")
     parser.add_argument("--threads", type=int, default=DEFAULT_THREADS, nargs="?",
                         help=f"Host threads reading / inflating the tables [{DEFAULT_THREADS}]")
+    parser.add_argument("--sweep", type=str, default=None,
+                        help="several count windows in one run, e.g. 1-255,2-255,1-3 (tables staged once; one .kma each)")
     return parser
 
 
@@ -71,8 +73,9 @@ def address_slice(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(n, lo + per)
 
 
-def gpu_partial(headers: List[Header], lo: int, hi: int, min_count: int, max_count: int, device: int, threads: int) -> np.ndarray:
-    """Stage addresses [lo, hi) of every table in HBM on `device` and tally them in one kernel pass."""
+def gpu_partial(headers: List[Header], lo: int, hi: int, windows, device: int, threads: int) -> List[np.ndarray]:
+    """Stage addresses [lo, hi) of every table in HBM on `device` ONCE and tally them with one kernel pass
+    per (min_count, max_count) window."""
     N = len(headers)
     bufs = [_lib.DeviceBuffer(hi - lo, device) for _ in range(N)]
 
@@ -82,32 +85,33 @@ def gpu_partial(headers: List[Header], lo: int, hi: int, min_count: int, max_cou
     try:
         with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
             list(pool.map(stage, range(N)))
-        part, _ = _lib.gram_device_partial([b.ptr for b in bufs], hi - lo, min_count, max_count, device=device)
+        parts = [_lib.gram_device_partial([b.ptr for b in bufs], hi - lo, mn, mx, device=device)[0] for mn, mx in windows]
     finally:
         for b in bufs:
             b.free()
-    return part
+    return parts
 
 
-def pair_matrix(headers: List[Header], min_count: int, max_count: int, threads: int = DEFAULT_THREADS, devices=(0,),
-                group=None, partial_fn=gpu_partial) -> np.ndarray:
-    """N x N u64: [i][i] = valid addresses of table i, [i][j] (i<j) = addresses valid in both.
+def pair_matrix(headers: List[Header], windows, threads: int = DEFAULT_THREADS, devices=(0,), group=None,
+                partial_fn=gpu_partial) -> List[np.ndarray]:
+    """One N x N u64 per (min, max) window: [i][i] = valid addresses of table i, [i][j] (i<j) = addresses valid in both.
 
     Single process: the address range is split over `devices`.  With `group` (a torch.distributed
     process group, or True for the default group) this rank scans only its own slice on devices[0]
-    and the N x N partials are summed by one all-reduce.  `partial_fn` computes one slice's tallies
-    (the GPU path above; the CPU-only distributed tests substitute the oracle)."""
-    n, N = headers[0].data_size, len(headers)
+    and the partials of all windows are summed by ONE all-reduce.  `partial_fn` computes one slice's
+    tallies (the GPU path above; the CPU-only distributed tests substitute the oracle)."""
+    n, N, W = headers[0].data_size, len(headers), len(windows)
     if group is not None:
         import torch.distributed as dist
         pg = None if group is True else group
         plan = [(devices[0],) + address_slice(n, dist.get_rank(pg), dist.get_world_size(pg))]
     else:
         plan = [(d,) + address_slice(n, i, len(devices)) for i, d in enumerate(devices)]
-    total = np.zeros((N, N), dtype=np.uint64)
+    total = np.zeros((W, N, N), dtype=np.uint64)
     for dev, lo, hi in plan:
         if hi > lo:
-            total += partial_fn(headers, lo, hi, min_count, max_count, dev, threads)
+            for w, part in enumerate(partial_fn(headers, lo, hi, windows, dev, threads)):
+                total[w] += part
     if group is not None:
         import torch
         import torch.distributed as dist
@@ -117,22 +121,27 @@ def pair_matrix(headers: List[Header], min_count: int, max_count: int, threads: 
             t = t.to(torch.device("cuda", devices[0]))
         dist.all_reduce(t, group=pg)                           # sum of the N x N partials (RCCL over xGMI on GPUs)
         total = t.cpu().numpy().view(np.uint64)
-    return total
+    return [total[w] for w in range(W)]
 
 
 def merge(project_name: str, indexes: List[Path], min_count: int = DEFAULT_MIN_COUNT, max_count: int = DEFAULT_MAX_COUNT,
           buffer_size: int = DEFAULT_BUFFER_SIZE, block_size: int = DEFAULT_BLOCK_SIZE, threads: int = DEFAULT_THREADS,
-          devices=(0,), group=None, partial_fn=gpu_partial):
-    """merger.py:80-210."""
-    assert min_count >= 1
-    assert max_count <= 255
+          devices=(0,), group=None, partial_fn=gpu_partial, windows=None):
+    """merger.py:80-210.  `windows` (a list of (min_count, max_count)) turns the call into a sweep: the
+    tables are staged once and one `.kma` + `.kma.json` is written per window (the reference re-runs
+    the whole merge per threshold, README.md:57-61); the first window's matrix is returned."""
+    windows = [(min_count, max_count)] if not windows else [tuple(w) for w in windows]
+    for mn, mx in windows:
+        assert mn >= 1
+        assert mx <= 255
     assert buffer_size > 0
     assert block_size > 0
     assert len(indexes) > 0
 
-    outfile = Path(f"{project_name}.{min_count:03d}-{max_count:03d}.kma")
+    outfiles = [Path(f"{project_name}.{mn:03d}-{mx:03d}.kma") for mn, mx in windows]
     assert not Path(project_name).exists(), f"project name ({project_name}) is a file. maybe forgot to pass project name as first argument?"
-    assert not outfile.exists(), f"project output file ({outfile}) already exists. not overwriting."
+    for outfile in outfiles:
+        assert not outfile.exists(), f"project output file ({outfile}) already exists. not overwriting."
 
     indexes = [Path(p) for p in indexes]
     assert all(i.exists() for i in indexes)
@@ -153,23 +162,26 @@ def merge(project_name: str, indexes: List[Path], min_count: int = DEFAULT_MIN_C
         data.append({"pos": pos, "index_file": kin, "description_file": desc, "header": header})
     print()
 
-    pair = pair_matrix(headers, min_count, max_count, threads=threads, devices=devices, group=group, partial_fn=partial_fn)
-    # (N,N,3): [k][l] = (total_k, total_l, shared) (merger.py:175-176); the diagonal, which the reference
-    # never assigns in its uninitialised array (merger.py:136), is zero here
-    matrix = _lib.gram_expand(pair)
-    for k in range(len(data) - 1):
-        for l in range(k + 1, len(data)):
-            print(f"   matrix Total #{k:3d} {int(matrix[k, l, 0]):15,d} Total #{l:3d} {int(matrix[k, l, 1]):15,d} Shared {int(matrix[k, l, 2]):15,d}")
-
+    pairs = pair_matrix(headers, windows, threads=threads, devices=devices, group=group, partial_fn=partial_fn)
     for v in data:
         v["header"] = v["header"].to_dict(lean=True)          # merger.py:187-188
-    output = {"project_name": project_name, "min_count": min_count, "max_count": max_count, "data": data}
-
     is_writer = True
     if group is not None:
         import torch.distributed as dist
         is_writer = dist.get_rank(None if group is True else group) == 0
-    if is_writer:
+
+    matrices = []
+    for (mn, mx), outfile, pair in zip(windows, outfiles, pairs):
+        # (N,N,3): [k][l] = (total_k, total_l, shared) (merger.py:175-176); the diagonal, which the reference
+        # never assigns in its uninitialised array (merger.py:136), is zero here
+        matrix = _lib.gram_expand(pair)
+        matrices.append(matrix)
+        for k in range(len(data) - 1):
+            for l in range(k + 1, len(data)):
+                print(f"   matrix Total #{k:3d} {int(matrix[k, l, 0]):15,d} Total #{l:3d} {int(matrix[k, l, 1]):15,d} Shared {int(matrix[k, l, 2]):15,d}")
+        if not is_writer:
+            continue
+        output = {"project_name": project_name, "min_count": mn, "max_count": mx, "data": data}
         outfile_json = Path(f"{outfile}.json")
         outfile_json_tmp = Path(f"{outfile_json}.tmp")
         print(f"saving {outfile_json}")
@@ -181,7 +193,16 @@ def merge(project_name: str, indexes: List[Path], min_count: int = DEFAULT_MIN_C
         with outfile_tmp.open(mode="wb") as fhd:
             np.savez_compressed(fhd, matrix=matrix)            # merger.py:207: key `matrix`
         outfile_tmp.rename(outfile)
-    return data, matrix
+    return data, matrices[0]
+
+
+def parse_sweep(text: str):
+    """`"1-255,2-255,1-3"` -> [(1, 255), (2, 255), (1, 3)]."""
+    out = []
+    for item in text.split(","):
+        lo, hi = item.strip().split("-")
+        out.append((int(lo), int(hi)))
+    return out
 
 
 def main(argv: List[str] = None) -> None:
@@ -194,4 +215,5 @@ def main(argv: List[str] = None) -> None:
     indexes.sort()                                             # matrix order = sorted path order (merger.py:228)
     devices = tuple(int(d) for d in os.environ.get("PK_DEVICES", "0").split(",") if d != "")
     merge(args.Project_Name, indexes, min_count=args.min_count, max_count=args.max_count, buffer_size=args.buffer_size,
-          block_size=args.block_size, threads=args.threads, devices=devices or (0,))
+          block_size=args.block_size, threads=args.threads, devices=devices or (0,),
+          windows=parse_sweep(args.sweep) if args.sweep else None)

@@ -33,7 +33,7 @@ def _worker(rank, world, port, workdir, paths, mn, mx):
 
         def partial(headers, lo, hi, *a):
             seen.append((lo, hi))
-            return _oracle_partial(headers, lo, hi, *a)
+            return _oracle_partial(headers, lo, hi, *a)              # (windows, device, threads) pass through
         data, matrix = merger.merge(os.path.join(workdir, "dist"), paths, min_count=mn, max_count=mx, group=True, partial_fn=partial)
         np.save(os.path.join(workdir, f"matrix_rank{rank}.npy"), matrix)
         np.save(os.path.join(workdir, f"slice_rank{rank}.npy"), np.array(seen))

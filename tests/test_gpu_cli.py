@@ -71,6 +71,11 @@ def test_merger_cli_matches_reference_matrix(gpu, tmp_path, manifest):
     assert sorted(meta.keys()) == case["kma_json_keys"]
     assert sorted(meta["data"][0]["header"].keys()) == case["kma_json_header_keys"]
     assert [os.path.basename(d["index_file"]) for d in meta["data"]] == case["order"]  # sorted, whatever the argv order
+    # a sweep stages the tables once and writes one .kma per window
+    sw = str(tmp_path / "sweep")
+    _run(os.path.join(ROOT, "merger.py"), sw, *kins, "--sweep", "1-3,2-255", cwd=str(tmp_path))
+    assert np.array_equal(np.load(sw + ".001-003.kma")["matrix"], m)
+    assert np.array_equal(np.load(sw + ".002-255.kma")["matrix"], np.array(manifest["merger"]["G7_k7_n13_min2"]["matrix"], dtype=np.uint64))
     # the pair API the reference's pool workers call (merger.py:62-78)
     from pykmer_amd import merger
     assert merger.calculate_distance(kins[0], kins[1], max_count=3) == tuple(int(x) for x in m[0, 1])

@@ -176,16 +176,19 @@ def test_timer():
 
 
 # ------------------------------------------------------------------ merger host logic -----------
-def _oracle_partial(headers, lo, hi, min_count, max_count, device, threads):
+def _oracle_partial(headers, lo, hi, windows, device, threads):
     tabs = [h.read_table()[lo:hi] for h in headers]
-    m = oracle.gram(tabs, min_count, max_count)
     N = len(tabs)
-    pair = np.zeros((N, N), np.uint64)
-    for i in range(N):
-        pair[i, i] = np.count_nonzero((tabs[i] >= min_count) & (tabs[i] <= max_count))
-        for j in range(i + 1, N):
-            pair[i, j] = m[i, j, 2]
-    return pair
+    parts = []
+    for min_count, max_count in windows:
+        m = oracle.gram(tabs, min_count, max_count)
+        pair = np.zeros((N, N), np.uint64)
+        for i in range(N):
+            pair[i, i] = np.count_nonzero((tabs[i] >= min_count) & (tabs[i] <= max_count))
+            for j in range(i + 1, N):
+                pair[i, j] = m[i, j, 2]
+        parts.append(pair)
+    return parts
 
 
 def _family_indexes(tmp_path, manifest, n=13):
@@ -219,6 +222,30 @@ def test_merge_writes_kma_like_reference(tmp_path, manifest):
     assert not os.path.exists(proj + ".002-005.kma.tmp")
     with pytest.raises(AssertionError):                                              # refuses to overwrite (merger.py:98-99)
         merger.merge(proj, sorted(paths), min_count=2, max_count=5, partial_fn=_oracle_partial)
+
+
+def test_merge_sweep_writes_one_kma_per_window(tmp_path, manifest):
+    """--min/--max sweeps in one run (tables staged once), each window equal to its own golden."""
+    paths = sorted(_family_indexes(tmp_path, manifest))
+    proj = str(tmp_path / "sweep")
+    wins = merger.parse_sweep("1-255, 2-255,1-3,2-5")
+    assert wins == [(1, 255), (2, 255), (1, 3), (2, 5)]
+    calls = []
+
+    def counting_partial(*a):
+        calls.append(a[3])
+        return _oracle_partial(*a)
+    data, first = merger.merge(proj, paths, partial_fn=counting_partial, windows=wins)
+    assert len(calls) == 1 and list(calls[0]) == wins                       # one staging pass for all windows
+    for (mn, mx), tag in zip(wins, ("default", "min2", "max3", "min2max5")):
+        want = np.array(manifest["merger"][f"G7_k7_n13_{tag}"]["matrix"], dtype=np.uint64)
+        got = np.load(f"{proj}.{mn:03d}-{mx:03d}.kma")["matrix"]
+        assert np.array_equal(got, want), tag
+        meta = json.load(open(f"{proj}.{mn:03d}-{mx:03d}.kma.json"))
+        assert meta["min_count"] == mn and meta["max_count"] == mx
+    assert np.array_equal(first, np.array(manifest["merger"]["G7_k7_n13_default"]["matrix"], dtype=np.uint64))
+    with pytest.raises(AssertionError):
+        merger.merge(str(tmp_path / "bad"), paths, partial_fn=_oracle_partial, windows=[(0, 5)])
 
 
 def test_merge_validation(tmp_path, manifest):
