@@ -74,7 +74,8 @@ int pk_indexer_feed(pk_indexer *ix, const uint8_t *host_fasta, uint64_t n_bytes)
 /* Same, but the bytes already sit in device memory on the indexer's device (16-byte aligned, < 4 GiB per
  * call).  Work runs on the indexer's own stream; the call returns when the feed has been counted. */
 int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uint64_t n_bytes);
-/* Close the last record and build the 256-bin value histogram of the u8 table, all in HBM.         */
+/* Close the last record and report the totals.  hist256_out[v] = number of table entries equal to v
+ * (the histogram is kept in HBM while counting, so this makes no pass over the table).              */
 int pk_indexer_finish(pk_indexer *ix, uint64_t *num_kmers_out, uint64_t *total_bp_out,
                       uint64_t hist256_out[256], uint64_t *n_recs_out);
 int pk_indexer_records(pk_indexer *ix, pk_record *recs_out, uint64_t recs_cap);
@@ -87,7 +88,7 @@ int pk_indexer_table_device(pk_indexer *ix, const void **dev_table_out);
 int pk_indexer_table_slice_to_device(pk_indexer *ix, void *dev_dst, uint64_t offset, uint64_t n_bytes);
 /* Seconds spent since the last reset per stage, measured with HIP events on the indexer's stream:
  * [0] structure scans, [1] k-mer walk kernel (extract + route; in direct mode extract + atomic count),
- * [2] histogram (direct mode: clamp+histogram), [3] table zeroing, [4] feeds (as a double),
+ * [2] finish (direct mode: clamp+histogram pass; otherwise next to nothing), [3] table zeroing, [4] feeds (as a double),
  * [5] partition passes, [6] bucket count + side list, [7] 1.0 if PK_COUNT_MODE=direct. */
 int pk_indexer_timings(pk_indexer *ix, double out[8]);
 void pk_indexer_destroy(pk_indexer *ix);

@@ -501,9 +501,47 @@ constexpr uint32_t K6_PIECE = 65024;   // multiple of 8
 
 // `fresh` = first feed after a reset: the table holds nothing yet (it is not even zeroed), so slices
 // are not read back and buckets without records are written as zeros.
+//
+// The value histogram behind Header.update_stats (tools.py:246-263) is maintained here as well: each
+// workgroup writes the net change it made as one row of 256 signed counters, k_hist_reduce adds the
+// rows to the running histogram, and finish() needs no pass over the table (3.3 ms at k=17).  Two ways
+// of getting that change, chosen per bucket:
+//   sparse bucket (records < addresses/4, the k=17 case): from the record side -- the LDS add returns
+//     the counter's previous value, so every add knows which bins it moves a k-mer between; counters
+//     preloaded from an earlier feed's slice make the change relative to what the table already held;
+//   dense bucket (the k=15 case): histogram of the slice stored minus histogram of the slice loaded,
+//     tallied on the packed dwords (bytes equal to 1 and 2 by SWAR test + popcount).
+// Bins 1 and 2 -- nearly everything -- live in two lane registers; the rest goes to 256 LDS bins.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    // rotate-and-add inside each row of 16 lanes (DPP row_ror 8/4/2/1), then add the four row sums
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
+struct SliceTally {
+    int d1 = 0, d2 = 0;
+    __device__ __forceinline__ void add_dword(int *dh, uint32_t x, int sign) {
+        const uint32_t z = swar_zero(x), one = swar_zero(x ^ 0x01010101u), two = swar_zero(x ^ 0x02020202u);
+        d1 += sign * (int)__builtin_popcount(one);
+        d2 += sign * (int)__builtin_popcount(two);
+        uint32_t rest = ~(z | one | two) & 0x80808080u;
+        while (rest) {
+            const int bit = __ffs(rest) - 1;                             // 7, 15, 23 or 31
+            atomicAdd(&dh[(x >> (bit - 7)) & 0xffu], sign);
+            rest &= rest - 1u;
+        }
+    }
+};
+
 __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
-                                                       uint32_t fb_bits, uint8_t *__restrict__ table8, uint32_t fresh) {
+                                                       uint32_t fb_bits, uint8_t *__restrict__ table8, uint32_t fresh,
+                                                       int *__restrict__ bucket_hist) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int dh[256];
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);                  // 2^fb_bits / 2 dwords
     const uint32_t fb = blockIdx.x;
     const uint32_t start = final_start[fb], end = final_start[fb + 1];
@@ -514,14 +552,23 @@ __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restric
             if (n_addr >= 16) for (uint32_t g = threadIdx.x; g < n_addr / 16; g += SC_T) reinterpret_cast<uint4 *>(slice)[g] = make_uint4(0, 0, 0, 0);
             else for (uint32_t a = threadIdx.x; a < n_addr; a += SC_T) slice[a] = 0;
         }
+        if (threadIdx.x < 256) bucket_hist[(uint64_t)fb * 256 + threadIdx.x] = 0;   // no change to the histogram
         return;                                                          // otherwise the slice stays as it is
     }
+    const bool by_rec = end - start < n_addr / 4 || n_addr < 16;         // sparse bucket: histogram change from the adds
+    SliceTally tally;
+    if (threadIdx.x < 256) dh[threadIdx.x] = 0;
     if (fresh) {
         for (uint32_t a = threadIdx.x; a < max(n_addr / 2, 1u); a += SC_T) cnt[a] = 0u;
     } else if (n_addr >= 16) {                                           // fold in what the slice already holds (earlier feeds)
+        if (!by_rec) __syncthreads();                                    // dh zeroed before anyone subtracts from it
         for (uint32_t g = threadIdx.x; g < n_addr / 16; g += SC_T) {
             uint4 v = reinterpret_cast<const uint4 *>(slice)[g];
             uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            if (!by_rec) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) tally.add_dword(dh, w[q], -1);
+            }
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 uint32_t lo = (w[q >> 1] >> (16 * (q & 1))) & 0xffu, hi = (w[q >> 1] >> (16 * (q & 1) + 8)) & 0xffu;
@@ -529,9 +576,23 @@ __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restric
             }
         }
     } else {
-        for (uint32_t a = threadIdx.x; a < n_addr / 2; a += SC_T) cnt[a] = (uint32_t)slice[2 * a] | ((uint32_t)slice[2 * a + 1] << 16);
+        for (uint32_t a = threadIdx.x; a < n_addr / 2; a += SC_T) cnt[a] = slice[2 * a] | ((uint32_t)slice[2 * a + 1] << 16);
     }
     __syncthreads();
+    auto bump = [&](uint32_t a, uint32_t n) {
+        const uint32_t sh = 16u * (a & 1u);
+        if (!by_rec) { atomicAdd(&cnt[a >> 1], n << sh); return; }
+        int &d1 = tally.d1, &d2 = tally.d2;
+        const uint32_t c = (atomicAdd(&cnt[a >> 1], n << sh) >> sh) & 0xffffu;
+        const uint32_t oc = c > 255u ? 255u : c, nc = c + n > 255u ? 255u : c + n;
+        if (oc == nc) return;                                            // already saturated
+        if (nc == 1u) d1++;
+        else if (nc == 2u && oc == 1u) { d2++; d1--; }
+        else {
+            atomicAdd(&dh[nc], 1);
+            if (oc) atomicAdd(&dh[oc], -1);
+        }
+    };
     const uint32_t base = start & ~7u;                                   // 16-byte aligned vector loads
     for (uint32_t p0 = base; p0 < end; p0 += K6_PIECE) {
         const uint32_t p1 = min(p0 + K6_PIECE, end);
@@ -547,11 +608,11 @@ __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restric
                 const uint32_t a = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
                 if (in && pn && a == pa) pn++;
                 else {
-                    if (pn) atomicAdd(&cnt[pa >> 1], pn << (16 * (pa & 1)));
+                    if (pn) bump(pa, pn);
                     pa = a; pn = in ? 1u : 0u;
                 }
             }
-            if (pn) atomicAdd(&cnt[pa >> 1], pn << (16 * (pa & 1)));
+            if (pn) bump(pa, pn);
         }
         __syncthreads();
         if (p1 < end) {                                                  // more to come: clamp so nothing can overflow
@@ -572,6 +633,10 @@ __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restric
                 lo = lo > 255u ? 255u : lo; hi = hi > 255u ? 255u : hi;
                 o[q >> 1] |= (lo | (hi << 8)) << (16 * (q & 1));
             }
+            if (!by_rec) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) tally.add_dword(dh, o[q], 1);
+            }
             reinterpret_cast<uint4 *>(slice)[g] = make_uint4(o[0], o[1], o[2], o[3]);
         }
     } else {
@@ -581,6 +646,28 @@ __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restric
             slice[2 * a + 1] = (uint8_t)(hi > 255u ? 255u : hi);
         }
     }
+    const int d1 = wave_sum_i32(tally.d1), d2 = wave_sum_i32(tally.d2);
+    if ((threadIdx.x & 63) == 0) {
+        if (d1) atomicAdd(&dh[1], d1);
+        if (d2) atomicAdd(&dh[2], d2);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) bucket_hist[(uint64_t)fb * 256 + threadIdx.x] = dh[threadIdx.x];
+}
+
+// sums the per-bucket histogram rows into the running 256-bin histogram (signed deltas: two's complement adds)
+__global__ __launch_bounds__(256) void k_hist_reduce(const int *__restrict__ bucket_hist, uint32_t n_rows, unsigned long long *__restrict__ hist) {
+    long long acc = 0;
+    uint32_t r = blockIdx.x;
+    for (; r + 7 * gridDim.x < n_rows; r += 8 * gridDim.x) {             // eight independent row loads in flight
+        int v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = bucket_hist[(uint64_t)(r + q * gridDim.x) * 256 + threadIdx.x];
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc += v[q];
+    }
+    for (; r < n_rows; r += gridDim.x) acc += bucket_hist[(uint64_t)r * 256 + threadIdx.x];
+    if (acc) atomicAdd(&hist[threadIdx.x], (unsigned long long)acc);
 }
 
 // ------------------------------------------------------------------ K7: fold the side list in ---
@@ -588,7 +675,7 @@ __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restric
 // added to the finished u8 table with a saturating compare-and-swap on the containing dword.
 constexpr uint32_t AS_SLOTS = 4096, AS_WGS = 64;
 
-__device__ __forceinline__ void table_sat_add(uint8_t *table8, uint64_t addr, uint32_t cnt) {
+__device__ __forceinline__ void table_sat_add(uint8_t *table8, uint64_t addr, uint32_t cnt, int *dh) {
     unsigned int *word = reinterpret_cast<unsigned int *>(table8 + (addr & ~3ull));
     const uint32_t sh = (uint32_t)(addr & 3ull) * 8u;
     unsigned int old = *word;
@@ -598,21 +685,27 @@ __device__ __forceinline__ void table_sat_add(uint8_t *table8, uint64_t addr, ui
         if (nb == b) return;
         unsigned int want = (old & ~(0xffu << sh)) | (nb << sh);
         unsigned int prev = atomicCAS(word, old, want);
-        if (prev == old) return;
+        if (prev == old) {                                               // the byte moved from b to nb: keep the histogram in step
+            atomicAdd(&dh[nb], 1);
+            if (b) atomicAdd(&dh[b], -1);
+            return;
+        }
         old = prev;
     }
 }
 
 __global__ __launch_bounds__(WG) void k_apply_side(const unsigned long long *__restrict__ side, const unsigned long long *__restrict__ side_n,
-                                                   uint64_t side_cap, uint8_t *__restrict__ table8) {
+                                                   uint64_t side_cap, uint8_t *__restrict__ table8, unsigned long long *__restrict__ hist) {
     __shared__ unsigned long long key[AS_SLOTS];
     __shared__ uint32_t val[AS_SLOTS];
+    __shared__ int dh[256];                                              // this workgroup's change to the value histogram
     unsigned long long n = *side_n;
     if (n > side_cap) n = side_cap;
     const unsigned long long per = (n + gridDim.x - 1) / gridDim.x;
     const unsigned long long lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
     if (lo >= hi) return;
     for (uint32_t i = threadIdx.x; i < AS_SLOTS; i += WG) { key[i] = 0ull; val[i] = 0u; }
+    dh[threadIdx.x & 255u] = 0;
     __syncthreads();
     for (unsigned long long i = lo + threadIdx.x; i < hi; i += WG) {
         const unsigned long long e = side[i];
@@ -630,11 +723,13 @@ __global__ __launch_bounds__(WG) void k_apply_side(const unsigned long long *__r
             }
             h = (h + 1u) & (AS_SLOTS - 1u);
         }
-        if (!done) table_sat_add(table8, addr, cnt > 255u ? 255u : cnt);
+        if (!done) table_sat_add(table8, addr, cnt > 255u ? 255u : cnt, dh);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < AS_SLOTS; i += WG)
-        if (key[i] != 0ull) table_sat_add(table8, key[i] - 1ull, val[i] > 255u ? 255u : val[i]);
+        if (key[i] != 0ull) table_sat_add(table8, key[i] - 1ull, val[i] > 255u ? 255u : val[i], dh);
+    __syncthreads();
+    if (threadIdx.x < 256 && dh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)(long long)dh[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ plan + launch sequence ------
@@ -680,12 +775,13 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
     lay->side_cap = n_bytes + 16;                          // every side entry stands for >= 1 k-mer
     lay->side = o; o += up((size_t)lay->side_cap * 8);
     lay->side_n = o; o += 256;
+    lay->bucket_hist = o; o += up((size_t)nfb * 256 * 4);
     return o;
 }
 
 int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, const PartPlan &pl,
                        uint8_t *ws, const PartWorkspace &lay, uint8_t *table8, DevRec *recs, uint64_t recs_cap, Carry *carry,
-                       hipStream_t s, hipEvent_t ev_walk_end, hipEvent_t ev_part_end, bool fresh) {
+                       hipStream_t s, hipEvent_t ev_walk_end, hipEvent_t ev_part_end, bool fresh, unsigned long long *hist) {
     uint32_t *cnt = (uint32_t *)(ws + lay.cnt), *hist1 = (uint32_t *)(ws + lay.hist1), *rowoff1 = (uint32_t *)(ws + lay.rowoff1);
     uint32_t *bucket_base = (uint32_t *)(ws + lay.bucket_base), *wg2_start = (uint32_t *)(ws + lay.wg2_start);
     uint32_t *final_start = (uint32_t *)(ws + lay.final_start), *hist2 = (uint32_t *)(ws + lay.hist2), *rowoff2 = (uint32_t *)(ws + lay.rowoff2);
@@ -729,8 +825,10 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     if (ev_part_end) hipEventRecord(ev_part_end, s);
     const uint32_t nfb = pl.B1 * pl.B2;
     const size_t lds6 = ((size_t)1 << pl.fb_bits) * 2 < 64 ? 64 : ((size_t)1 << pl.fb_bits) * 2;
-    hipLaunchKernelGGL(k_bucket_count, dim3(nfb), dim3(SC_T), lds6, s, final_recs, final_start, pl.fb_bits, table8, fresh ? 1u : 0u);
-    hipLaunchKernelGGL(k_apply_side, dim3(AS_WGS), dim3(WG), 0, s, side, side_n, lay.side_cap, table8);
+    int *bucket_hist = (int *)(ws + lay.bucket_hist);
+    hipLaunchKernelGGL(k_bucket_count, dim3(nfb), dim3(SC_T), lds6, s, final_recs, final_start, pl.fb_bits, table8, fresh ? 1u : 0u, bucket_hist);
+    hipLaunchKernelGGL(k_hist_reduce, dim3(nfb < 16u ? 1u : (nfb / 16u > 2048u ? 2048u : nfb / 16u)), dim3(256), 0, s, (const int *)bucket_hist, nfb, hist);
+    hipLaunchKernelGGL(k_apply_side, dim3(AS_WGS), dim3(WG), 0, s, side, side_n, lay.side_cap, table8, hist);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

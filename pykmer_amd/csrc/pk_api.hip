@@ -260,7 +260,7 @@ extern "C" int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uin
         }
         HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
         if (launch_partitioned(f, n_bytes, ix->bytes_fed, ix->lane_state, ix->c_l2s, pl, ix->ws, lay, ix->table8, ix->recs, ix->recs_cap,
-                               ix->carry, ix->stream, ix->ev[3], ix->ev[8], ix->table_fresh))
+                               ix->carry, ix->stream, ix->ev[3], ix->ev[8], ix->table_fresh, ix->hist))
             return fail(PK_ERR_HIP, "partition pipeline launch failed: %s", hipGetErrorString(hipGetLastError()));
         ix->table_fresh = false;
         HIPCHK(hipEventRecord(ix->ev[9], ix->stream));
@@ -307,7 +307,7 @@ extern "C" int pk_indexer_finish(pk_indexer *ix, uint64_t *num_kmers_out, uint64
                 HIPCHK(hipMemsetAsync(ix->table8, 0, std::max<uint64_t>(ix->n, 16), ix->stream));
                 ix->table_fresh = false;
             }
-            launch_hist8(ix->table8, ix->n, ix->hist, ix->stream);
+            // the value histogram was kept up to date by k_bucket_count / k_apply_side: no pass over the table
         }
         HIPCHK(hipEventRecord(ix->ev[5], ix->stream));
         HIPCHK(hipGetLastError());

@@ -48,14 +48,14 @@ struct PartPlan {
     uint32_t dbg;            // PK_DEBUG_WALK ablation bits (timing diagnostics only; 0 in production)
 };
 struct PartWorkspace {       // byte offsets into one device allocation
-    size_t flat, cnt, hist1, rowoff1, bucket_base, wg2_start, final_start, out1, hist2, rowoff2, out2, side, side_n;
+    size_t flat, cnt, hist1, rowoff1, bucket_base, wg2_start, final_start, out1, hist2, rowoff2, out2, side, side_n, bucket_hist;
     uint64_t side_cap;
 };
 PartPlan make_part_plan(uint32_t k, uint64_t n_bytes);
 size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace *lay);
 int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, const PartPlan &pl,
                        uint8_t *ws, const PartWorkspace &lay, uint8_t *table8, DevRec *recs, uint64_t recs_cap, Carry *carry,
-                       hipStream_t s, hipEvent_t ev_walk_end, hipEvent_t ev_part_end, bool fresh);
+                       hipStream_t s, hipEvent_t ev_walk_end, hipEvent_t ev_part_end, bool fresh, unsigned long long *hist);
 
 // gram_scan.hip
 // tables: device array of N device pointers, each n_slice bytes (16-byte aligned).  pair: device N*N u64,

@@ -129,6 +129,33 @@ def test_streaming_feed_equals_one_shot(gpu):
                 for f in ("name_off", "name_len", "seq_len", "n_valid_kmers"):
                     assert np.array_equal(recs[f], want["records"][f]), (k, trial, f)
                 assert np.array_equal(ix.table_to_host(), want["table"])
+                assert np.array_equal(fin["hist256"][1:], oracle.table_stats(want["table"])[0]), (k, trial)
+
+
+@pytest.mark.parametrize("k", [9, 11])
+def test_histogram_kept_across_dense_and_sparse_feeds(gpu, k):
+    """The value histogram is maintained feed by feed (k_bucket_count): buckets that receive many records
+    and buckets that receive few take different tally paths, on a fresh table and on top of earlier
+    feeds; saturated counters must stop moving between bins."""
+    import synth
+    dense, _ = synth.generate(11, 3_000_000, 3, pm_dup=200, pm_tandem=100)
+    sparse, _ = synth.generate(12, 1_500, 1)
+    again, _ = synth.generate(13, 1_000_000, 2, pm_tandem=300)
+    hot = np.frombuffer(b">hot\n" + b"ACGTTGCAAC" * 4000 + b"\n", dtype=np.uint8)       # pushes a few addresses past 255
+    pieces = [sparse, dense, hot, sparse, again, hot]
+    whole = np.concatenate(pieces)
+    want = oracle.count_fasta(whole, k)
+    for upto in range(1, len(pieces) + 1):                              # every prefix: the last feed lands on a different history
+        part = oracle.count_fasta(np.concatenate(pieces[:upto]), k)
+        with gpu.Indexer(k) as ix:
+            for piece in pieces[:upto]:
+                ix.feed(piece)
+            fin = ix.finish()
+            assert np.array_equal(fin["hist256"][1:], oracle.table_stats(part["table"])[0]), upto
+            assert int(fin["hist256"].sum()) == 4 ** k
+            if upto == len(pieces):
+                assert np.array_equal(ix.table_to_host(), want["table"])
+                assert fin["num_kmers"] == want["num_kmers"]
 
 
 def test_random_structure_fuzz(gpu):
