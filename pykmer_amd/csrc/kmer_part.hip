@@ -155,42 +155,43 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
         const bool walk_clean = __all(!lane_state_dirty(lst) && ls_in != LS_HEADER && st2.p_tail == 0);
         wk.begin(ls_in, st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
 
-        REC0 *region = flat + ((uint64_t)c * (WG / 64) + wave) * SUB;
+        // wave-uniform base of this wave's record region (kept in scalar registers: stores use saddr + lane offset)
+        const uint64_t region_i = ((uint64_t)c * (WG / 64) + wave) * SUB;
+        REC0 *region = flat + (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(region_i >> 32)) << 32) |
+                               __builtin_amdgcn_readfirstlane((uint32_t)region_i));
         uint32_t wcount = 0;                               // wave-uniform
         // wave-uniform call: ballot-compact this step's records into the wave's region (coalesced store)
         const uint32_t dbg = DBG ? pl.dbg : 0u;          // ablation bits exist only in the diagnostic instantiation
         auto wave_emit = [&](bool e, KT a) {
-            unsigned long long m = __ballot(e);
+            const unsigned long long m = __ballot(e);
             if (e) {
-                uint32_t p = wcount + __popcll(m & ((1ull << lane) - 1ull));
-                if (!(dbg & 4u)) region[p] = (REC0)a;
-                if (!(dbg & 2u)) atomicAdd(&hist1[(uint32_t)((uint64_t)a >> shift1)], 1u);
+                const uint32_t p = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (!(dbg & 4u)) *reinterpret_cast<REC0 *>(reinterpret_cast<char *>(region) + p * (uint32_t)sizeof(REC0)) = (REC0)a;   // 32-bit lane offset
+                const uint32_t digit = sizeof(KT) == 4 ? (uint32_t)a >> (shift1 & 31u) : (uint32_t)((uint64_t)a >> shift1);
+                if (!(dbg & 2u)) atomicAdd(&hist1[digit], 1u);
             }
             wcount += __popcll(m);
         };
         // The lane remembers its last three distinct k-mers.  A k-mer is emitted the first time it is seen;
         // seeing it again while remembered (tandem repeats of period 1-3: the contended buckets) only
         // bumps a counter, which goes to the workgroup's LDS table when the entry is evicted or the piece
-        // ends.  Either route counts each k-mer exactly once.
+        // ends.  Either route counts each k-mer exactly once.  a1, a2, a3 are pairwise distinct (an entry
+        // is only ever inserted on a miss; the initial ~0 is no k-mer), so at most one compare hits.
         KT a1 = ~(KT)0, a2 = ~(KT)0, a3 = ~(KT)0;
         uint32_t n1 = 0, n2 = 0, n3 = 0;
-        // written with 0/1 integers rather than bools: every compare is consumed at once, which keeps the
-        // number of live wave masks (SGPR pairs) in this loop small
-        auto route = [&](bool has_b, KT canon) {
-            const uint32_t has = has_b ? 1u : 0u;
-            const uint32_t m1 = has & (canon == a1 ? 1u : 0u);
-            const uint32_t m2 = has & (canon == a2 ? 1u : 0u) & (m1 ^ 1u);
-            const uint32_t m3 = has & (canon == a3 ? 1u : 0u) & ((m1 | m2) ^ 1u);
-            const uint32_t miss = has & ((m1 | m2 | m3) ^ 1u);
-            n1 += m1; n2 += m2; n3 += m3;
-            const bool missb = miss != 0u;
-            const uint32_t ev_n = missb ? n3 : 0u;
+        auto route = [&](bool has, KT canon) {
+            const bool e1 = canon == a1, e2 = canon == a2, e3 = canon == a3;
+            const bool miss = has & !(e1 | e2 | e3);                  // plain mask logic, no short-circuit branches
+            n1 += (has & e1) ? 1u : 0u;
+            n2 += (has & e2) ? 1u : 0u;
+            n3 += (has & e3) ? 1u : 0u;
+            const uint32_t ev_n = miss ? n3 : 0u;
             const KT ev_a = a3;
-            a3 = missb ? a2 : a3; n3 = missb ? n2 : n3;
-            a2 = missb ? a1 : a2; n2 = missb ? n1 : n2;
-            a1 = missb ? canon : a1; n1 = missb ? 0u : n1;
-            wave_emit((dbg & 1u) ? has_b : missb, canon);
-            if (__ballot(ev_n != 0u)) hot_insert_wave(&hot, (unsigned long long)ev_a, ev_n, side, side_n, side_cap);
+            a3 = miss ? a2 : a3; n3 = miss ? n2 : n3;
+            a2 = miss ? a1 : a2; n2 = miss ? n1 : n2;
+            a1 = miss ? canon : a1; n1 = miss ? 0u : n1;
+            wave_emit((dbg & 1u) ? has : miss, canon);
+            if (ev_n != 0u) hot_insert(hot, (uint64_t)ev_a, ev_n, side, side_n, side_cap);   // rare: leaving a tandem run
         };
         if (dbg & 8u) {
         } else if (walk_clean) {                             // the common case: plain sequence lines
@@ -537,32 +538,43 @@ struct SliceTally {
     }
 };
 
-__global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
-                                                       uint32_t fb_bits, uint8_t *__restrict__ table8, uint32_t fresh,
-                                                       int *__restrict__ bucket_hist) {
+// `split_bits` > 0 (sparse tables, k=17): a bucket is shared by 2^split_bits workgroups, each reading all of the
+// bucket's (few) records but counting only its own part of the address range -- the LDS counters shrink
+// with the part, so several workgroups fit on a CU and hide each other's phases.
+template <int T>
+__global__ __launch_bounds__(T) void k_bucket_count(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
+                                                    uint32_t fb_bits, uint32_t split_bits, uint8_t *__restrict__ table8, uint32_t fresh,
+                                                    int *__restrict__ bucket_hist) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int dh[256];
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);                  // 2^fb_bits / 2 dwords
-    const uint32_t fb = blockIdx.x;
+    const uint32_t fb = blockIdx.x >> split_bits, part = blockIdx.x & ((1u << split_bits) - 1u);
     const uint32_t start = final_start[fb], end = final_start[fb + 1];
-    const uint32_t n_addr = 1u << fb_bits;
-    uint8_t *slice = table8 + (uint64_t)fb * n_addr;
+    const uint32_t part_bits = fb_bits - split_bits;
+    const uint32_t n_addr = 1u << part_bits;                             // addresses this workgroup owns
+    uint8_t *slice = table8 + ((uint64_t)fb << fb_bits) + (uint64_t)part * n_addr;
     if (start == end) {
         if (fresh) {                                                     // nothing counted here: the slice is all zero
-            if (n_addr >= 16) for (uint32_t g = threadIdx.x; g < n_addr / 16; g += SC_T) reinterpret_cast<uint4 *>(slice)[g] = make_uint4(0, 0, 0, 0);
-            else for (uint32_t a = threadIdx.x; a < n_addr; a += SC_T) slice[a] = 0;
+            if (n_addr >= 16) for (uint32_t g = threadIdx.x; g < n_addr / 16; g += T) reinterpret_cast<uint4 *>(slice)[g] = make_uint4(0, 0, 0, 0);
+            else for (uint32_t a = threadIdx.x; a < n_addr; a += T) slice[a] = 0;
         }
-        if (threadIdx.x < 256) bucket_hist[(uint64_t)fb * 256 + threadIdx.x] = 0;   // no change to the histogram
+        for (uint32_t i = threadIdx.x; i < 256; i += T) bucket_hist[(uint64_t)blockIdx.x * 256 + i] = 0;   // no change to the histogram
         return;                                                          // otherwise the slice stays as it is
     }
-    const bool by_rec = end - start < n_addr / 4 || n_addr < 16;         // sparse bucket: histogram change from the adds
+    // the first 16 bytes of records every lane will need are requested before the counters are set up, so the
+    // load's latency hides behind that phase (sparse buckets need no second load at all)
+    const uint32_t base = start & ~7u;                                   // 16-byte aligned vector loads
+    const uint32_t i_first = base + threadIdx.x * 8;
+    uint4 v_first = make_uint4(0, 0, 0, 0);
+    if (i_first < min(base + K6_PIECE, end)) v_first = *reinterpret_cast<const uint4 *>(recs + i_first);
+    const bool by_rec = ((end - start) >> split_bits) < n_addr / 4 || n_addr < 16;         // sparse bucket: histogram change from the adds
     SliceTally tally;
-    if (threadIdx.x < 256) dh[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i < 256; i += T) dh[i] = 0;
     if (fresh) {
-        for (uint32_t a = threadIdx.x; a < max(n_addr / 2, 1u); a += SC_T) cnt[a] = 0u;
+        for (uint32_t a = threadIdx.x; a < max(n_addr / 2, 1u); a += T) cnt[a] = 0u;
     } else if (n_addr >= 16) {                                           // fold in what the slice already holds (earlier feeds)
         if (!by_rec) __syncthreads();                                    // dh zeroed before anyone subtracts from it
-        for (uint32_t g = threadIdx.x; g < n_addr / 16; g += SC_T) {
+        for (uint32_t g = threadIdx.x; g < n_addr / 16; g += T) {
             uint4 v = reinterpret_cast<const uint4 *>(slice)[g];
             uint32_t w[4] = {v.x, v.y, v.z, v.w};
             if (!by_rec) {
@@ -576,7 +588,7 @@ __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restric
             }
         }
     } else {
-        for (uint32_t a = threadIdx.x; a < n_addr / 2; a += SC_T) cnt[a] = slice[2 * a] | ((uint32_t)slice[2 * a + 1] << 16);
+        for (uint32_t a = threadIdx.x; a < n_addr / 2; a += T) cnt[a] = slice[2 * a] | ((uint32_t)slice[2 * a + 1] << 16);
     }
     __syncthreads();
     auto bump = [&](uint32_t a, uint32_t n) {
@@ -593,19 +605,19 @@ __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restric
             if (oc) atomicAdd(&dh[oc], -1);
         }
     };
-    const uint32_t base = start & ~7u;                                   // 16-byte aligned vector loads
     for (uint32_t p0 = base; p0 < end; p0 += K6_PIECE) {
         const uint32_t p1 = min(p0 + K6_PIECE, end);
-        for (uint32_t i = p0 + threadIdx.x * 8; i < p1; i += SC_T * 8) {
-            uint4 v = *reinterpret_cast<const uint4 *>(recs + i);
+        for (uint32_t i = p0 + threadIdx.x * 8; i < p1; i += T * 8) {
+            const uint4 v = i == i_first ? v_first : *reinterpret_cast<const uint4 *>(recs + i);
             uint32_t w[4] = {v.x, v.y, v.z, v.w};
             // the lane's 8 records, equal neighbours merged (what is left of tandem runs arrives back to back)
             uint32_t pa = 0, pn = 0;
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const uint32_t idx = i + q;
-                const bool in = idx >= start && idx < end;
-                const uint32_t a = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                const uint32_t full = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+                const bool in = idx >= start && idx < end && (full >> part_bits) == part;
+                const uint32_t a = full & (n_addr - 1u);
                 if (in && pn && a == pa) pn++;
                 else {
                     if (pn) bump(pa, pn);
@@ -616,7 +628,7 @@ __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restric
         }
         __syncthreads();
         if (p1 < end) {                                                  // more to come: clamp so nothing can overflow
-            for (uint32_t a = threadIdx.x; a < max(n_addr / 2, 1u); a += SC_T) {
+            for (uint32_t a = threadIdx.x; a < max(n_addr / 2, 1u); a += T) {
                 uint32_t x = cnt[a], lo = x & 0xffffu, hi = x >> 16;
                 cnt[a] = (lo > 255u ? 255u : lo) | ((hi > 255u ? 255u : hi) << 16);
             }
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restric
     }
     // clamp to u8 and write the slice back, 16 addresses per lane
     if (n_addr >= 16) {
-        for (uint32_t g = threadIdx.x; g < n_addr / 16; g += SC_T) {
+        for (uint32_t g = threadIdx.x; g < n_addr / 16; g += T) {
             uint32_t o[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int q = 0; q < 8; q++) {
@@ -640,7 +652,7 @@ __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restric
             reinterpret_cast<uint4 *>(slice)[g] = make_uint4(o[0], o[1], o[2], o[3]);
         }
     } else {
-        for (uint32_t a = threadIdx.x; a < n_addr / 2; a += SC_T) {
+        for (uint32_t a = threadIdx.x; a < n_addr / 2; a += T) {
             uint32_t x = cnt[a], lo = x & 0xffffu, hi = x >> 16;
             slice[2 * a] = (uint8_t)(lo > 255u ? 255u : lo);
             slice[2 * a + 1] = (uint8_t)(hi > 255u ? 255u : hi);
@@ -652,7 +664,7 @@ __global__ __launch_bounds__(SC_T) void k_bucket_count(const uint16_t *__restric
         if (d2) atomicAdd(&dh[2], d2);
     }
     __syncthreads();
-    if (threadIdx.x < 256) bucket_hist[(uint64_t)fb * 256 + threadIdx.x] = dh[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < 256; i += T) bucket_hist[(uint64_t)blockIdx.x * 256 + i] = dh[i];
 }
 
 // sums the per-bucket histogram rows into the running 256-bin histogram (signed deltas: two's complement adds)
@@ -775,7 +787,7 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
     lay->side_cap = n_bytes + 16;                          // every side entry stands for >= 1 k-mer
     lay->side = o; o += up((size_t)lay->side_cap * 8);
     lay->side_n = o; o += 256;
-    lay->bucket_hist = o; o += up((size_t)nfb * 256 * 4);
+    lay->bucket_hist = o; o += up((size_t)nfb * 4 * 256 * 4);              // up to 4 workgroups per bucket
     return o;
 }
 
@@ -790,7 +802,8 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     hipFuncSetAttribute((const void *)k_scatter1<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_scatter1<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_WIDE);
     hipFuncSetAttribute((const void *)k_scatter2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
-    hipFuncSetAttribute((const void *)k_bucket_count, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute((const void *)k_bucket_count<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute((const void *)k_bucket_count<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (hipMemsetAsync(side_n, 0, 8, s) != hipSuccess) return -2;
     if (pl.dbg && pl.k <= 15) {                              // diagnostic build of the walk (PK_DEBUG_WALK), timing only
         hipLaunchKernelGGL((k_walk_flat<uint32_t, uint32_t, true>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, pl,
@@ -824,10 +837,20 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     }
     if (ev_part_end) hipEventRecord(ev_part_end, s);
     const uint32_t nfb = pl.B1 * pl.B2;
-    const size_t lds6 = ((size_t)1 << pl.fb_bits) * 2 < 64 ? 64 : ((size_t)1 << pl.fb_bits) * 2;
+    // sparse tables (few records per 2^16-address bucket, k=17): 2^split workgroups per bucket, see k_bucket_count
+    uint32_t split = 0, k6_threads = 1024;
+    if (pl.fb_bits == 16 && n / nfb < 8192) { split = 1; }
+    if (const char *e = getenv("PK_K6_SPLIT")) { uint32_t v = (uint32_t)atoi(e); if (pl.fb_bits == 16 && v <= 2) split = v; }
+    if (const char *e = getenv("PK_K6_THREADS")) { if (atoi(e) == 512) k6_threads = 512; }
+    const size_t part_addrs = (size_t)1 << (pl.fb_bits - split);
+    const size_t lds6 = part_addrs * 2 < 64 ? 64 : part_addrs * 2;
     int *bucket_hist = (int *)(ws + lay.bucket_hist);
-    hipLaunchKernelGGL(k_bucket_count, dim3(nfb), dim3(SC_T), lds6, s, final_recs, final_start, pl.fb_bits, table8, fresh ? 1u : 0u, bucket_hist);
-    hipLaunchKernelGGL(k_hist_reduce, dim3(nfb < 16u ? 1u : (nfb / 16u > 2048u ? 2048u : nfb / 16u)), dim3(256), 0, s, (const int *)bucket_hist, nfb, hist);
+    const uint32_t n_rows6 = (uint32_t)(nfb << split);
+    if (k6_threads == 512)
+        hipLaunchKernelGGL(k_bucket_count<512>, dim3(n_rows6), dim3(512), lds6, s, final_recs, final_start, pl.fb_bits, split, table8, fresh ? 1u : 0u, bucket_hist);
+    else
+        hipLaunchKernelGGL(k_bucket_count<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, final_start, pl.fb_bits, split, table8, fresh ? 1u : 0u, bucket_hist);
+    hipLaunchKernelGGL(k_hist_reduce, dim3(n_rows6 < 16u ? 1u : (n_rows6 / 16u > 2048u ? 2048u : n_rows6 / 16u)), dim3(256), 0, s, (const int *)bucket_hist, n_rows6, hist);
     hipLaunchKernelGGL(k_apply_side, dim3(AS_WGS), dim3(WG), 0, s, side, side_n, lay.side_cap, table8, hist);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
