@@ -180,6 +180,8 @@ __device__ __forceinline__ L2 wg_excl_scan_l2(const L2 &mine, const L2 &seed, L2
 
 // ---- staging: one 16 KiB chunk, coalesced 16 B per lane, into padded LDS pieces ----------------
 // fasta must be 16-byte aligned.  Bytes at or beyond n_bytes are never read from memory.
+// Bytes past the end of the stream are staged as 0, which every consumer treats like a terminator or
+// skips by length (the clean-piece walk relies on "byte <= 13 is no sequence character").
 __device__ __forceinline__ void stage_chunk(const uint8_t *__restrict__ fasta, uint64_t chunk_base, uint64_t n_bytes,
                                             uint8_t *lds) {
 #pragma unroll
@@ -227,7 +229,8 @@ __device__ __forceinline__ void for_each_byte(const uint8_t *lds, uint32_t nb, F
 }
 
 // L1 summary of the lane's piece.  `dirty` comes back true if the piece holds anything besides
-// sequence characters and line terminators (a blank other than \n / \r, or a '>'): such pieces need
+// sequence characters and line terminators (a blank or control byte other than \n / \r, or a '>';
+// the clean-piece loops rely on "byte > 13 means sequence character"): such pieces need
 // the full state machine; pieces that are not dirty and do not start inside a header line are
 // "clean" and take the short paths below and in kmer_walk.h.
 __device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb, bool &dirty) {
@@ -239,7 +242,7 @@ __device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb, bool &di
         const bool opens = act && st == LS_START && !ws;
         st = term ? (uint32_t)LS_START : opens ? (gt ? (uint32_t)LS_HEADER : (uint32_t)LS_SEQ) : st;
         ht |= term;
-        d |= act && ((ws && !term) || gt);
+        d |= act && (((ws || c < 0x21u) && !term) || gt);
     });
     dirty = d;
     return nb ? l1_make(ht, st) : 0u;

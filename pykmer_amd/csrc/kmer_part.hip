@@ -286,13 +286,13 @@ constexpr size_t SCATTER_LDS_WIDE = sizeof(ScatterLds);            // 104 KiB
 template <typename RIN, bool WIDE>
 __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PER], const bool (&ok)[SC_PER], uint32_t n_tile,
                                              uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out) {
-    uint32_t dg[SC_PER], rk[SC_PER];
+    uint32_t dr[SC_PER];                                   // digit (9 bits) | rank inside the tile << 9
 #pragma unroll
     for (int j = 0; j < SC_PER; j++) {
-        dg[j] = 0; rk[j] = 0;
+        dr[j] = 0;
         if (ok[j]) {
-            dg[j] = (uint32_t)((uint64_t)r[j] >> shift) & (B - 1u);
-            rk[j] = atomicAdd(&L.hist[dg[j]], 1u);
+            const uint32_t dg = (uint32_t)((uint64_t)r[j] >> shift) & (B - 1u);
+            dr[j] = dg | (atomicAdd(&L.hist[dg], 1u) << 9);
         }
     }
     __syncthreads();
@@ -317,8 +317,9 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
 #pragma unroll
     for (int j = 0; j < SC_PER; j++)
         if (ok[j]) {
-            uint32_t p = L.off[dg[j]] + rk[j];
-            if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)dg[j]; }
+            const uint32_t dg = dr[j] & 511u;
+            const uint32_t p = L.off[dg] + (dr[j] >> 9);
+            if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)dg; }
             else L.rec[p] = (uint32_t)r[j];
         }
     __syncthreads();
@@ -381,25 +382,54 @@ __global__ __launch_bounds__(SC_T) void k_scatter1(const REC0 *__restrict__ flat
     if (threadIdx.x < B) L.run[threadIdx.x] = bucket_base[threadIdx.x] + rowoff[(uint64_t)blockIdx.x * B + threadIdx.x];
     __syncthreads();
     const uint32_t c_lo = blockIdx.x * pl.G, c_hi = min(c_lo + pl.G, pl.n_chunks);
+    // one tile = the four wave regions of one chunk (SUB slots each, n[s] of them filled).  Thread t takes
+    // slots 4t .. 4t+3 of every region with one 16-byte (32-byte for 64-bit records) load; slots past
+    // n[s] are allocated but hold no record -- they are read anyway and masked, which keeps the loads
+    // branch-free.
+    static_assert(SUB == 4 * SC_T && SC_PER == 16, "tile layout");
+    struct TileMeta { uint32_t n[4], total; };
+    auto meta = [&](uint32_t c) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(cnt + (uint64_t)c * 4);
+        TileMeta t;
+        t.n[0] = v.x; t.n[1] = v.y; t.n[2] = v.z; t.n[3] = v.w;
+        t.total = v.x + v.y + v.z + v.w;
+        return t;
+    };
+    struct alignas(sizeof(REC0) * 4) Quad { REC0 v[4]; };
+    auto fetch = [&](uint32_t c, REC0 (&r)[SC_PER]) {
+        const Quad *src = reinterpret_cast<const Quad *>(flat + (uint64_t)c * 4 * SUB) + threadIdx.x;
+#pragma unroll
+        for (int sreg = 0; sreg < 4; sreg++) {
+            const Quad q = src[sreg * (SUB / 4)];
+#pragma unroll
+            for (int e = 0; e < 4; e++) r[sreg * 4 + e] = q.v[e];
+        }
+    };
+    // 32-bit records: the next chunk's loads are issued before the current tile is sorted, so they fly
+    // during its barriers (64-bit records would not fit the register budget twice)
+    constexpr bool AHEAD = true;
+    REC0 nxt[AHEAD ? SC_PER : 1];
+    TileMeta tn = {{0, 0, 0, 0}, 0};
+    if constexpr (AHEAD) {
+        if (c_lo < c_hi) { tn = meta(c_lo); fetch(c_lo, nxt); }
+    }
     for (uint32_t c = c_lo; c < c_hi; c++) {
-        const uint32_t n0 = cnt[c * 4 + 0], n1 = cnt[c * 4 + 1], n2 = cnt[c * 4 + 2], n3 = cnt[c * 4 + 3];
-        const uint32_t p1 = n0, p2 = n0 + n1, p3 = p2 + n2, n_tile = p3 + n3;
-        if (n_tile == 0) continue;
-        const REC0 *src = flat + (uint64_t)c * 4 * SUB;
         REC0 r[SC_PER];
+        TileMeta t;
+        if constexpr (AHEAD) {
+            t = tn;
+#pragma unroll
+            for (int j = 0; j < SC_PER; j++) r[j] = nxt[j];
+            if (c + 1 < c_hi) { tn = meta(c + 1); fetch(c + 1, nxt); }
+        } else {
+            t = meta(c);
+            if (t.total) fetch(c, r);
+        }
+        if (t.total == 0) continue;
         bool ok[SC_PER];
 #pragma unroll
-        for (int j = 0; j < SC_PER; j++) {
-            uint32_t i = threadIdx.x + j * SC_T;
-            ok[j] = i < n_tile;
-            r[j] = 0;
-            if (ok[j]) {
-                uint32_t s = (i >= p1) + (i >= p2) + (i >= p3);
-                uint32_t pre = s == 0 ? 0u : s == 1 ? p1 : s == 2 ? p2 : p3;
-                r[j] = src[s * SUB + (i - pre)];
-            }
-        }
-        scatter_tile<REC0, sizeof(REC0) == 8>(L, r, ok, n_tile, shift, B, low_mask, out16, out);
+        for (int j = 0; j < SC_PER; j++) ok[j] = threadIdx.x * 4u + (j & 3) < t.n[j >> 2];
+        scatter_tile<REC0, sizeof(REC0) == 8>(L, r, ok, t.total, shift, B, low_mask, out16, out);
     }
 }
 
@@ -475,7 +505,19 @@ __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ 
     __syncthreads();
     if (threadIdx.x < B) L.run[threadIdx.x] = final_start[(uint64_t)b * B + threadIdx.x] + rowoff[(uint64_t)blockIdx.x * B + threadIdx.x];
     __syncthreads();
-    // 16-byte aligned windows of TILE records over [lo, hi); the first / last window are partly masked
+    // 16-byte aligned windows of TILE records over [lo, hi); the first / last window are partly masked.
+    // The next window's loads are issued before the current tile is sorted, so they fly during its barriers.
+    auto fetch = [&](uint32_t win, uint4 (&v)[SC_PER / 4]) {
+        const uint32_t v_hi = min(hi, win + (uint32_t)TILE);
+#pragma unroll
+        for (int j = 0; j < SC_PER / 4; j++) {
+            const uint32_t i = win + (threadIdx.x + j * SC_T) * 4u;
+            v[j] = make_uint4(0, 0, 0, 0);
+            if (i < v_hi) v[j] = *reinterpret_cast<const uint4 *>(in + i);
+        }
+    };
+    uint4 nxt[SC_PER / 4];
+    fetch(lo & ~3u, nxt);
     for (uint32_t win = lo & ~3u; win < hi; win += TILE) {
         const uint32_t v_lo = max(lo, win), v_hi = min(hi, win + (uint32_t)TILE);
         const uint32_t n_tile = v_hi - v_lo;
@@ -484,12 +526,11 @@ __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ 
 #pragma unroll
         for (int j = 0; j < SC_PER / 4; j++) {
             const uint32_t i = win + (threadIdx.x + j * SC_T) * 4u;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (i < v_hi) v = *reinterpret_cast<const uint4 *>(in + i);
-            const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t q[4] = {nxt[j].x, nxt[j].y, nxt[j].z, nxt[j].w};
 #pragma unroll
             for (int e = 0; e < 4; e++) { ok[j * 4 + e] = i + e >= v_lo && i + e < v_hi; r[j * 4 + e] = q[e]; }
         }
+        if (win + TILE < hi) fetch(win + TILE, nxt);
         scatter_tile<uint32_t, false>(L, r, ok, n_tile, shift, B, low_mask, true, out);
     }
 }

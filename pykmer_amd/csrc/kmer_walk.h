@@ -118,10 +118,15 @@ struct Walker {
     __device__ __forceinline__ void walk_clean(const uint8_t *lds, uint32_t nb, Sink &&sink) {
         const uint4 *mine = reinterpret_cast<const uint4 *>(lds + threadIdx.x * LDS_STRIDE);
         KT f = fwd, r = rev;
-        uint32_t rn = run, n_seq = 0, n_kmer = 0;
-        const uint32_t kk = k, live = rec != 0 ? 1u : 0u;
+        uint32_t n_seq = 0, n_kmer = 0;
+        const uint32_t kk = k;
+        const bool live = rec != 0;
+        uint32_t need = kk - run;                                        // bases still missing for a full window
         // 16 bytes per ds_read_b128, fetched one iteration ahead; the 16 byte steps are unrolled with
-        // constant shifts (a rolled byte loop made the compiler issue one LDS read + full wait per byte)
+        // constant shifts (a rolled byte loop made the compiler issue one LDS read + full wait per byte).
+        // Bytes past the end of the stream were staged as 0 (stage_chunk) and behave like terminators here,
+        // so `nb` is not consulted.
+        (void)nb;
         uint4 nxt = mine[0];
 #pragma unroll 1
         for (uint32_t q = 0; q < (uint32_t)PIECE / 16u; q++) {
@@ -130,23 +135,26 @@ struct Walker {
             const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll 16
             for (uint32_t j = 0; j < 16u; j++) {
-                uint32_t c = (w[j >> 2] >> (8u * (j & 3u))) & 0xffu;
-                c = (q * 16u + j < nb) ? c : 10u;                        // past the end: behaves like a terminator
-                const uint32_t seq = (c != 10u && c != 13u) ? 1u : 0u;
-                const uint32_t b = (c >> 1) & 3u, code = b ^ (b >> 1);
-                const uint32_t valid = (c >> 6) == 1u ? ((0x0010008Au >> (c & 31u)) & 1u) : 0u;
+                const uint32_t c = (w[j >> 2] >> (8u * (j & 3u))) & 0xffu;
+                const bool seq = c > 13u;                                // clean piece: anything but \n / \r (/ 0 fill) is sequence text
+                // bits 1-2 of the letter pick the 2-bit code (A 0, C 1, T 3, G 2) and the letter it must be
+                const uint32_t idx2 = c & 6u;
+                const uint32_t code = (0xB4u >> idx2) & 3u;
+                const uint32_t expect = (0x47544341u >> (idx2 << 2)) & 0xffu;       // 'A' 'C' 'T' 'G'
+                const bool valid = (c & 0xDFu) == expect;                // either case; everything else is no base
                 const KT nf = (KT)(((f << 2) | (KT)code) & mask);        // indexer.py:149
-                const KT nr = (KT)((r >> 2) | ((KT)(3u - code) << top)); // indexer.py:150
+                const KT nr = (KT)((r >> 2) | ((KT)(3u ^ code) << top)); // indexer.py:150
                 f = valid ? nf : f;
                 r = valid ? nr : r;
-                const uint32_t grown = rn < kk ? rn + 1u : rn;
-                rn = valid ? grown : (seq ? 0u : rn);
-                const bool has = (valid & live) != 0u && rn == kk;
-                n_seq += seq;
+                const uint32_t fewer = __builtin_elementwise_sub_sat(need, valid ? 1u : 0u);
+                need = (seq & !valid) ? kk : fewer;                      // a non-base restarts the window, a terminator holds it
+                const bool has = valid & live & (need == 0u);
+                n_seq += seq ? 1u : 0u;
                 n_kmer += has ? 1u : 0u;
                 sink(has, (KT)(f < r ? f : r));
             }
         }
+        const uint32_t rn = kk - need;
         fwd = f; rev = r; run = rn;
         seq_acc += n_seq; kmer_acc += n_kmer;
     }

@@ -158,6 +158,24 @@ def test_histogram_kept_across_dense_and_sparse_feeds(gpu, k):
                 assert fin["num_kmers"] == want["num_kmers"]
 
 
+def test_control_bytes_inside_sequence_lines(gpu):
+    """Bytes below 0x21 other than \\n / \\r (NUL, \\x01, tab, VT, FS..US, space) and DEL inside sequence
+    text: blanks are stripped at line ends and map to None inside, the rest are plain non-bases.  Such
+    pieces must leave the clean-piece fast path, also in the last, partly filled chunk."""
+    rng = np.random.default_rng(77)
+    body = rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), size=70_000)
+    odd = np.frombuffer(b"\x00\x01\x08\x09\x0b\x0c\x0e\x1b\x1c\x1f \x7f", dtype=np.uint8)
+    at = rng.choice(body.size, size=600, replace=False)
+    body[at] = rng.choice(odd, size=at.size)
+    body[-40:] = np.frombuffer(b"ACGTACGTAC\x01GTACGTACGT\x00ACGTACGTACGTACG\x1fTA", dtype=np.uint8)   # tail piece
+    lines = [b">ctl one"]
+    for i in range(0, body.size, 61):
+        lines.append(body[i:i + 61].tobytes())
+    data = np.frombuffer(b"\n".join(lines), dtype=np.uint8)           # no trailing newline
+    for k in (5, 9, 15):
+        _check_against_oracle(gpu, data, k)
+
+
 def test_random_structure_fuzz(gpu):
     """Random byte soup over the FASTA-relevant alphabet: every parser state transition, every seam."""
     rng = np.random.default_rng(11)
