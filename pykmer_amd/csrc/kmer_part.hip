@@ -178,18 +178,20 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
         // ends.  Either route counts each k-mer exactly once.  a1, a2, a3 are pairwise distinct (an entry
         // is only ever inserted on a miss; the initial ~0 is no k-mer), so at most one compare hits.
         KT a1 = ~(KT)0, a2 = ~(KT)0, a3 = ~(KT)0;
-        uint32_t n1 = 0, n2 = 0, n3 = 0;
+        uint32_t nn = 0;
         auto route = [&](bool has, KT canon) {
             const bool e1 = canon == a1, e2 = canon == a2, e3 = canon == a3;
-            const bool miss = has & !(e1 | e2 | e3);                  // plain mask logic, no short-circuit branches
-            n1 += (has & e1) ? 1u : 0u;
-            n2 += (has & e2) ? 1u : 0u;
-            n3 += (has & e3) ? 1u : 0u;
-            const uint32_t ev_n = miss ? n3 : 0u;
+            const bool h1 = has & e1, h2 = has & e2, h3 = has & e3;
+            const bool miss = has & !e1 & !e2 & !e3;
+            // the three counters live in one register (7 bits each are plenty: a piece has 64 steps, and
+            // the entries are drained after every piece): n1 | n2 << 8 | n3 << 16
+            nn += h1 ? 1u : (h2 ? 0x100u : (h3 ? 0x10000u : 0u));
+            const uint32_t ev_n = miss ? (nn >> 16) : 0u;
             const KT ev_a = a3;
-            a3 = miss ? a2 : a3; n3 = miss ? n2 : n3;
-            a2 = miss ? a1 : a2; n2 = miss ? n1 : n2;
-            a1 = miss ? canon : a1; n1 = miss ? 0u : n1;
+            a3 = miss ? a2 : a3;
+            a2 = miss ? a1 : a2;
+            a1 = miss ? canon : a1;
+            nn = miss ? ((nn << 8) & 0xffff00u) : nn;
             wave_emit((dbg & 1u) ? has : miss, canon);
             if (ev_n != 0u) hot_insert(hot, (uint64_t)ev_a, ev_n, side, side_n, side_cap);   // rare: leaving a tandem run
         };
@@ -203,9 +205,9 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
                 route(has, canon);
             });
         }
-        hot_insert_wave(&hot, (unsigned long long)a1, n1, side, side_n, side_cap);     // drain the lane's entries
-        hot_insert_wave(&hot, (unsigned long long)a2, n2, side, side_n, side_cap);
-        hot_insert_wave(&hot, (unsigned long long)a3, n3, side, side_n, side_cap);
+        hot_insert_wave(&hot, (unsigned long long)a1, nn & 0xffu, side, side_n, side_cap);     // drain the lane's entries
+        hot_insert_wave(&hot, (unsigned long long)a2, (nn >> 8) & 0xffu, side, side_n, side_cap);
+        hot_insert_wave(&hot, (unsigned long long)a3, nn >> 16, side, side_n, side_cap);
         wk.flush_rec_wave();
         if (lane == 0) cnt[c * (WG / 64) + wave] = wcount;
         __syncthreads();                                   // pieces consumed; LDS may be restaged

@@ -119,7 +119,10 @@ struct Walker {
         const uint4 *mine = reinterpret_cast<const uint4 *>(lds + threadIdx.x * LDS_STRIDE);
         KT f = fwd, r = rev;
         uint32_t n_seq = 0, n_kmer = 0;
-        const uint32_t kk = k;
+        // k is wanted as a vector operand in every step (select against a lane mask); pin one copy in a
+        // VGPR instead of letting the compiler re-create it from a spilled scalar each time
+        uint32_t kk;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(kk) : "s"(k));
         const bool live = rec != 0;
         uint32_t need = kk - run;                                        // bases still missing for a full window
         // 16 bytes per ds_read_b128, fetched one iteration ahead; the 16 byte steps are unrolled with
