@@ -310,7 +310,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
         for (int i = 0; i < w; i++) pre += L.wsum[i];
         if (threadIdx.x < B) {
             L.off[threadIdx.x] = pre + inc - v;
-            L.gbase[threadIdx.x] = L.run[threadIdx.x];
+            L.gbase[threadIdx.x] = L.run[threadIdx.x] - (pre + inc - v);   // sorted position p of digit d goes to p + gbase[d]
             L.run[threadIdx.x] += v;
             L.hist[threadIdx.x] = 0;                          // ready for the next tile
         }
@@ -336,12 +336,12 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
                 const uint32_t r0 = L.rec[p], r1 = p + 1 < n_tile ? L.rec[p + 1] : 0u;
                 const uint32_t d0 = WIDE ? L.dig[p] : (r0 >> shift) & (B - 1u);
                 const uint32_t d1 = p + 1 < n_tile ? (WIDE ? (uint32_t)L.dig[p + 1] : (r1 >> shift) & (B - 1u)) : ~0u;
-                const uint32_t dst0 = L.gbase[d0] + (p - L.off[d0]);
+                const uint32_t dst0 = p + L.gbase[d0];
                 if (d0 == d1 && (dst0 & 1u) == 0u) {
                     *reinterpret_cast<uint32_t *>(o16 + dst0) = (r0 & low_mask) | ((r1 & low_mask) << 16);
                 } else {
                     o16[dst0] = (uint16_t)(r0 & low_mask);
-                    if (p + 1 < n_tile) o16[L.gbase[d1] + (p + 1 - L.off[d1])] = (uint16_t)(r1 & low_mask);
+                    if (p + 1 < n_tile) o16[p + 1 + L.gbase[d1]] = (uint16_t)(r1 & low_mask);
                 }
             }
         }
@@ -355,12 +355,12 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
                 const uint32_t r0 = L.rec[p], r1 = p + 1 < n_tile ? L.rec[p + 1] : 0u;
                 const uint32_t d0 = WIDE ? L.dig[p] : (r0 >> shift) & (B - 1u);
                 const uint32_t d1 = p + 1 < n_tile ? (WIDE ? (uint32_t)L.dig[p + 1] : (r1 >> shift) & (B - 1u)) : ~0u;
-                const uint32_t dst0 = L.gbase[d0] + (p - L.off[d0]);
+                const uint32_t dst0 = p + L.gbase[d0];
                 if (d0 == d1 && (dst0 & 1u) == 0u) {
                     *reinterpret_cast<uint2 *>(o32 + dst0) = make_uint2(r0 & low_mask, r1 & low_mask);
                 } else {
                     o32[dst0] = r0 & low_mask;
-                    if (p + 1 < n_tile) o32[L.gbase[d1] + (p + 1 - L.off[d1])] = r1 & low_mask;
+                    if (p + 1 < n_tile) o32[p + 1 + L.gbase[d1]] = r1 & low_mask;
                 }
             }
         }
