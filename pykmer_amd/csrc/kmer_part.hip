@@ -648,11 +648,23 @@ __global__ __launch_bounds__(T) void k_bucket_count(const uint16_t *__restrict__
             if (oc) atomicAdd(&dh[oc], -1);
         }
     };
+    constexpr int NIT = (K6_PIECE + T * 8 - 1) / (T * 8);               // 16-byte loads per lane and piece
     for (uint32_t p0 = base; p0 < end; p0 += K6_PIECE) {
         const uint32_t p1 = min(p0 + K6_PIECE, end);
-        for (uint32_t i = p0 + threadIdx.x * 8; i < p1; i += T * 8) {
-            const uint4 v = i == i_first ? v_first : *reinterpret_cast<const uint4 *>(recs + i);
-            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        // all of the piece's loads are issued before the first record is counted: one memory latency per
+        // piece instead of one per 8 records
+        uint4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const uint32_t i = p0 + (threadIdx.x + it * T) * 8;
+            v[it] = make_uint4(0, 0, 0, 0);
+            if (i < p1) v[it] = (it == 0 && p0 == base) ? v_first : *reinterpret_cast<const uint4 *>(recs + i);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const uint32_t i = p0 + (threadIdx.x + it * T) * 8;
+            if (i >= p1) continue;
+            const uint32_t w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
             // the lane's 8 records, equal neighbours merged (what is left of tandem runs arrives back to back)
             uint32_t pa = 0, pn = 0;
 #pragma unroll
