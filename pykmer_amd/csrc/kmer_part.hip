@@ -584,8 +584,9 @@ struct SliceTally {
 // `split_bits` > 0 (sparse tables, k=17): a bucket is shared by 2^split_bits workgroups, each reading all of the
 // bucket's (few) records but counting only its own part of the address range -- the LDS counters shrink
 // with the part, so several workgroups fit on a CU and hide each other's phases.
+// At most 64 vector registers: two of these 1024-thread workgroups must fit on a CU.
 template <int T>
-__global__ __launch_bounds__(T) void k_bucket_count(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bucket_count(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
                                                     uint32_t fb_bits, uint32_t split_bits, uint8_t *__restrict__ table8, uint32_t fresh,
                                                     int *__restrict__ bucket_hist) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -648,46 +649,54 @@ __global__ __launch_bounds__(T) void k_bucket_count(const uint16_t *__restrict__
             if (oc) atomicAdd(&dh[oc], -1);
         }
     };
-    constexpr int NIT = (K6_PIECE + T * 8 - 1) / (T * 8);               // 16-byte loads per lane and piece
-    for (uint32_t p0 = base; p0 < end; p0 += K6_PIECE) {
-        const uint32_t p1 = min(p0 + K6_PIECE, end);
-        // all of the piece's loads are issued before the first record is counted: one memory latency per
-        // piece instead of one per 8 records
-        uint4 v[NIT];
+    // the lane's 8 records starting at index i, equal neighbours merged (what is left of tandem runs arrives
+    // back to back)
+    auto count8 = [&](const uint4 &v, uint32_t i) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t pa = 0, pn = 0;
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const uint32_t i = p0 + (threadIdx.x + it * T) * 8;
-            v[it] = make_uint4(0, 0, 0, 0);
-            if (i < p1) v[it] = (it == 0 && p0 == base) ? v_first : *reinterpret_cast<const uint4 *>(recs + i);
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const uint32_t i = p0 + (threadIdx.x + it * T) * 8;
-            if (i >= p1) continue;
-            const uint32_t w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
-            // the lane's 8 records, equal neighbours merged (what is left of tandem runs arrives back to back)
-            uint32_t pa = 0, pn = 0;
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const uint32_t idx = i + q;
-                const uint32_t full = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-                const bool in = idx >= start && idx < end && (full >> part_bits) == part;
-                const uint32_t a = full & (n_addr - 1u);
-                if (in && pn && a == pa) pn++;
-                else {
-                    if (pn) bump(pa, pn);
-                    pa = a; pn = in ? 1u : 0u;
-                }
+        for (int q = 0; q < 8; q++) {
+            const uint32_t idx = i + q;
+            const uint32_t full = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+            const bool in = idx >= start && idx < end && (full >> part_bits) == part;
+            const uint32_t a = full & (n_addr - 1u);
+            if (in && pn && a == pa) pn++;
+            else {
+                if (pn) bump(pa, pn);
+                pa = a; pn = in ? 1u : 0u;
             }
-            if (pn) bump(pa, pn);
         }
+        if (pn) bump(pa, pn);
+    };
+    constexpr int NIT = (K6_PIECE + T * 8 - 1) / (T * 8);               // 16-byte loads per lane and piece
+    if (end - base <= (uint32_t)T * 8u) {                                // sparse bucket: the hoisted load was all of it
+        if (i_first < end) count8(v_first, i_first);
         __syncthreads();
-        if (p1 < end) {                                                  // more to come: clamp so nothing can overflow
-            for (uint32_t a = threadIdx.x; a < max(n_addr / 2, 1u); a += T) {
-                uint32_t x = cnt[a], lo = x & 0xffffu, hi = x >> 16;
-                cnt[a] = (lo > 255u ? 255u : lo) | ((hi > 255u ? 255u : hi) << 16);
+    } else {
+        for (uint32_t p0 = base; p0 < end; p0 += K6_PIECE) {
+            const uint32_t p1 = min(p0 + K6_PIECE, end);
+            // all of the piece's loads are issued before the first record is counted: one memory latency per
+            // piece instead of one per 8 records
+            uint4 v[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const uint32_t i = p0 + (threadIdx.x + it * T) * 8;
+                v[it] = make_uint4(0, 0, 0, 0);
+                if (i < p1) v[it] = (it == 0 && p0 == base) ? v_first : *reinterpret_cast<const uint4 *>(recs + i);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const uint32_t i = p0 + (threadIdx.x + it * T) * 8;
+                if (i < p1) count8(v[it], i);
             }
             __syncthreads();
+            if (p1 < end) {                                              // more to come: clamp so nothing can overflow
+                for (uint32_t a = threadIdx.x; a < max(n_addr / 2, 1u); a += T) {
+                    uint32_t x = cnt[a], lo = x & 0xffffu, hi = x >> 16;
+                    cnt[a] = (lo > 255u ? 255u : lo) | ((hi > 255u ? 255u : hi) << 16);
+                }
+                __syncthreads();
+            }
         }
     }
     // clamp to u8 and write the slice back, 16 addresses per lane
@@ -842,7 +851,7 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
     lay->side_cap = n_bytes + 16;                          // every side entry stands for >= 1 k-mer
     lay->side = o; o += up((size_t)lay->side_cap * 8);
     lay->side_n = o; o += 256;
-    lay->bucket_hist = o; o += up((size_t)nfb * 4 * 256 * 4);              // up to 4 workgroups per bucket
+    lay->bucket_hist = o; o += up((size_t)nfb * 2 * 256 * 4);              // up to 2 workgroups per bucket
     return o;
 }
 
@@ -858,7 +867,6 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     hipFuncSetAttribute((const void *)k_scatter1<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_WIDE);
     hipFuncSetAttribute((const void *)k_scatter2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_bucket_count<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    hipFuncSetAttribute((const void *)k_bucket_count<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (hipMemsetAsync(side_n, 0, 8, s) != hipSuccess) return -2;
     if (pl.dbg && pl.k <= 15) {                              // diagnostic build of the walk (PK_DEBUG_WALK), timing only
         hipLaunchKernelGGL((k_walk_flat<uint32_t, uint32_t, true>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, pl,
@@ -893,18 +901,12 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     if (ev_part_end) hipEventRecord(ev_part_end, s);
     const uint32_t nfb = pl.B1 * pl.B2;
     // sparse tables (few records per 2^16-address bucket, k=17): 2^split workgroups per bucket, see k_bucket_count
-    uint32_t split = 0, k6_threads = 1024;
-    if (pl.fb_bits == 16 && n / nfb < 8192) { split = 1; }
-    if (const char *e = getenv("PK_K6_SPLIT")) { uint32_t v = (uint32_t)atoi(e); if (pl.fb_bits == 16 && v <= 2) split = v; }
-    if (const char *e = getenv("PK_K6_THREADS")) { if (atoi(e) == 512) k6_threads = 512; }
+    const uint32_t split = (pl.fb_bits == 16 && n / nfb < 8192) ? 1u : 0u;
     const size_t part_addrs = (size_t)1 << (pl.fb_bits - split);
     const size_t lds6 = part_addrs * 2 < 64 ? 64 : part_addrs * 2;
     int *bucket_hist = (int *)(ws + lay.bucket_hist);
     const uint32_t n_rows6 = (uint32_t)(nfb << split);
-    if (k6_threads == 512)
-        hipLaunchKernelGGL(k_bucket_count<512>, dim3(n_rows6), dim3(512), lds6, s, final_recs, final_start, pl.fb_bits, split, table8, fresh ? 1u : 0u, bucket_hist);
-    else
-        hipLaunchKernelGGL(k_bucket_count<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, final_start, pl.fb_bits, split, table8, fresh ? 1u : 0u, bucket_hist);
+    hipLaunchKernelGGL(k_bucket_count<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, final_start, pl.fb_bits, split, table8, fresh ? 1u : 0u, bucket_hist);
     hipLaunchKernelGGL(k_hist_reduce, dim3(n_rows6 < 16u ? 1u : (n_rows6 / 16u > 2048u ? 2048u : n_rows6 / 16u)), dim3(256), 0, s, (const int *)bucket_hist, n_rows6, hist);
     hipLaunchKernelGGL(k_apply_side, dim3(AS_WGS), dim3(WG), 0, s, side, side_n, lay.side_cap, table8, hist);
     return hipGetLastError() == hipSuccess ? 0 : -2;
