@@ -126,8 +126,10 @@ struct PairBlocks {               // which 8x8 table-block pairs this launch tal
     int8_t bi[MAX_PB], bj[MAX_PB];
 };
 
-template <int SLOTS, bool FAST>
-__global__ __launch_bounds__(512) void k_gram_blk(const uint8_t *const *__restrict__ tables, int N, uint64_t n, ValidParams vp,
+// SLOTS pair blocks per wave: 1 (7-12 pair blocks, N 25-32: one wave each, 64 accumulators per lane, more
+// waves sharing the load phase), 2 or 3 otherwise (see launch_gram).
+template <int SLOTS, bool FAST, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_gram_blk(const uint8_t *const *__restrict__ tables, int N, uint64_t n, ValidParams vp,
                                                   PairBlocks pbs, unsigned long long *__restrict__ pair) {
     extern __shared__ uint32_t masks[];                 // [NB*BLK][TILE_WORDS]
     const int NB = (N + BLK - 1) / BLK;
@@ -252,20 +254,27 @@ int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int m
         pbs.n = 0;
         auto flush = [&]() {
             if (!pbs.n) return;
-            const int slots = pbs.n <= 16 ? 2 : 3;         // 128 / 192 accumulators per lane
+            // accumulators per lane: 64 / 128 / 192.  Measured at k=15: 6 blocks (N 17-24) 5.5 TB/s with 2 slots
+            // (3 waves, several workgroups per CU) vs 4.6 with 1; 10 blocks (N 25-32) 5.1 TB/s with 1 slot vs 4.2 with 2
+            const int slots = pbs.n <= 6 ? 2 : pbs.n <= 12 ? 1 : pbs.n <= 16 ? 2 : 3;
             const int waves = (pbs.n + slots - 1) / slots;
             if (lds > 64u * 1024u) {                       // opt in to more than 64 KiB of dynamic LDS
-                hipFuncSetAttribute((const void *)k_gram_blk<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void *)k_gram_blk<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void *)k_gram_blk<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void *)k_gram_blk<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<1, true, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<1, false, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<2, true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<2, false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<3, true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<3, false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             }
-            if (slots == 2) {
-                if (fast) hipLaunchKernelGGL((k_gram_blk<2, true>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
-                else hipLaunchKernelGGL((k_gram_blk<2, false>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+            if (slots == 1) {
+                if (fast) hipLaunchKernelGGL((k_gram_blk<1, true, 768>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+                else hipLaunchKernelGGL((k_gram_blk<1, false, 768>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+            } else if (slots == 2) {
+                if (fast) hipLaunchKernelGGL((k_gram_blk<2, true, 512>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+                else hipLaunchKernelGGL((k_gram_blk<2, false, 512>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
             } else {
-                if (fast) hipLaunchKernelGGL((k_gram_blk<3, true>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
-                else hipLaunchKernelGGL((k_gram_blk<3, false>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+                if (fast) hipLaunchKernelGGL((k_gram_blk<3, true, 512>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+                else hipLaunchKernelGGL((k_gram_blk<3, false, 512>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
             }
             pbs.n = 0;
         };
