@@ -163,9 +163,11 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
         // wave-uniform call: ballot-compact this step's records into the wave's region (coalesced store)
         const uint32_t dbg = DBG ? pl.dbg : 0u;          // ablation bits exist only in the diagnostic instantiation
         auto wave_emit = [&](bool e, KT a) {
-            const unsigned long long m = __ballot(e);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(e);   // takes the lane mask as it is (__ballot goes through an int)
             if (e) {
-                const uint32_t p = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                // inside the branch the execution mask IS the ballot: rank among the emitting lanes from it
+                const unsigned long long live = __builtin_amdgcn_read_exec();
+                const uint32_t p = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
                 if (!(dbg & 4u)) *reinterpret_cast<REC0 *>(reinterpret_cast<char *>(region) + p * (uint32_t)sizeof(REC0)) = (REC0)a;   // 32-bit lane offset
                 const uint32_t digit = sizeof(KT) == 4 ? (uint32_t)a >> (shift1 & 31u) : (uint32_t)((uint64_t)a >> shift1);
                 if (!(dbg & 2u)) atomicAdd(&hist1[digit], 1u);

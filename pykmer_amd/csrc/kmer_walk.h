@@ -124,7 +124,7 @@ struct Walker {
         uint32_t kk;
         asm volatile("v_mov_b32 %0, %1" : "=v"(kk) : "s"(k));
         const bool live = rec != 0;
-        uint32_t need = kk - run;                                        // bases still missing for a full window
+        int need = (int)(kk - run);                                      // bases still missing for a full window (<= 0: none)
         // 16 bytes per ds_read_b128, fetched one iteration ahead; the 16 byte steps are unrolled with
         // constant shifts (a rolled byte loop made the compiler issue one LDS read + full wait per byte).
         // Bytes past the end of the stream were staged as 0 (stage_chunk) and behave like terminators here,
@@ -149,15 +149,15 @@ struct Walker {
                 const KT nr = (KT)((r >> 2) | ((KT)(3u ^ code) << top)); // indexer.py:150
                 f = valid ? nf : f;
                 r = valid ? nr : r;
-                const uint32_t fewer = __builtin_elementwise_sub_sat(need, valid ? 1u : 0u);
-                need = (seq & !valid) ? kk : fewer;                      // a non-base restarts the window, a terminator holds it
-                const bool has = valid & live & (need == 0u);
+                const int fewer = need - (valid ? 1 : 0);                // may run below zero; a piece is far too short to wrap
+                need = (seq & !valid) ? (int)kk : fewer;                 // a non-base restarts the window, a terminator holds it
+                const bool has = valid & live & (need <= 0);
                 n_seq += seq ? 1u : 0u;
                 n_kmer += has ? 1u : 0u;
                 sink(has, (KT)(f < r ? f : r));
             }
         }
-        const uint32_t rn = kk - need;
+        const uint32_t rn = need <= 0 ? kk : kk - (uint32_t)need;
         fwd = f; rev = r; run = rn;
         seq_acc += n_seq; kmer_acc += n_kmer;
     }
