@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--no-merge32", action="store_true", help="skip the 32-table merge (config 5 shape)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-bp", type=int, default=160_000_000, help="sample size for the CPU baseline")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="threads of the all-cores CPU leg (capped by the process's CPU affinity; 16 = one GPU's host share)")
     args = ap.parse_args()
 
     import torch
@@ -195,6 +197,21 @@ def main():
         out["cpu_baseline"] = {"value": bp / dt, "unit": "bp/s", "cores": 1, "kind": "port",
                                "sample": f"oracle/kmer_oracle.c on a {bp / 1e6:.0f} Mbp C2-profile genome at k={k} ({dt:.1f} s)",
                                "host_cores_available": os.cpu_count()}
+        # the same port on the host cores this process may use, on the WHOLE workload; its table is also
+        # compared with the one the GPU built -- a second, independent full-size parity check
+        threads = max(1, min(args.cpu_threads, len(os.sched_getaffinity(0))))
+        step()                                                          # the merge section reused the indexer: recount
+        gpu_table = ix.table_to_host()
+        t0 = time.perf_counter()
+        mt = oracle.count_fasta_mt(fasta, k, threads)
+        dt_mt = time.perf_counter() - t0
+        if mt is not None:
+            same = bool(mt["num_kmers"] == fin["num_kmers"] and mt["total_bp"] == total_bp and np.array_equal(mt["table"], gpu_table))
+            out["cpu_baseline"]["all_cores"] = {"value": total_bp / dt_mt, "unit": "bp/s", "cores": threads, "kind": "port",
+                                                "sample": f"oracle/kmer_oracle_mt.c on the whole {total_bp / 1e6:.0f} Mbp workload at k={k} ({dt_mt:.1f} s)",
+                                                "table_equals_gpu_table": same}
+            assert same, "all-cores CPU port and GPU disagree"
+        del gpu_table, mt
         # the like-for-like anchor for the reference's 0.5 Mbp/s: its O(k)-per-window Python algorithm, restated
         from oracle import pyoracle
         small, sbp = synth.c2(300_000, seed=2)

@@ -1,7 +1,8 @@
 """oracle -- CPU restatement of the reference's hot path.  TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
-`kmer_oracle.c` (fast, streaming) is built with gcc into oracle/_build/; `pyoracle.py` is the
+`kmer_oracle.c` (fast, streaming) and `kmer_oracle_mt.c` (the same count on all cores, for the
+bench baseline) are built with gcc into oracle/_build/; `pyoracle.py` is the
 literal pure-Python twin for small cases.  The reference is pure Python, so there is no
 oracle/_ref build: the pin is tests/golden/, written by oracle/gen_golden.py running the reference.
 """
@@ -20,11 +21,11 @@ RECORD_DTYPE = np.dtype([("name_off", "<u8"), ("name_len", "<u8"), ("seq_len", "
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "kmer_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "kmer_oracle.c"), os.path.join(_HERE, "kmer_oracle_mt.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
         tmp = f"{_SO}.{os.getpid()}.tmp"               # several ranks may build at once: write aside, rename atomically
-        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", src, "-o", tmp])
+        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", *srcs, "-o", tmp])
         os.replace(tmp, _SO)
     return _SO
 
@@ -37,6 +38,9 @@ def _load():
         lib.pko_count_fasta.restype = ctypes.c_int
         lib.pko_count_fasta.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p,
                                         u64p, u64p, ctypes.c_void_p, ctypes.c_uint64, u64p]
+        lib.pko_count_fasta_mt.restype = ctypes.c_int
+        lib.pko_count_fasta_mt.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, u64p, u64p,
+                                           ctypes.c_int]
         lib.pko_table_stats.restype = ctypes.c_int
         lib.pko_table_stats.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
         lib.pko_gram.restype = ctypes.c_int
@@ -66,6 +70,23 @@ def count_fasta(fasta, k: int, table: np.ndarray = None):
         cap = int(nr.value)                       # rare: re-run only to collect every record
     return {"table": table, "num_kmers": int(nk.value), "total_bp": int(bp.value),
             "records": recs[: nr.value].copy()}
+
+
+def count_fasta_mt(fasta, k: int, threads: int, table: np.ndarray = None):
+    """All-cores variant (kmer_oracle_mt.c): dict(table, num_kmers, total_bp), or None when the input has
+    blanks other than line terminators (not handled there -- use count_fasta)."""
+    lib = _load()
+    buf = np.frombuffer(fasta, dtype=np.uint8) if isinstance(fasta, (bytes, bytearray)) else np.ascontiguousarray(fasta)
+    if table is None:
+        table = np.zeros(4 ** k, dtype=np.uint8)
+    nk, bp = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    rc = lib.pko_count_fasta_mt(buf.ctypes.data, buf.size, k, table.ctypes.data, ctypes.byref(nk), ctypes.byref(bp),
+                                int(threads))
+    if rc < 0:
+        raise ValueError(f"oracle rejected k={k}")
+    if rc == 1:
+        return None
+    return {"table": table, "num_kmers": int(nk.value), "total_bp": int(bp.value)}
 
 
 def chromosomes(fasta, records) -> list:

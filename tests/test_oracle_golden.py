@@ -135,3 +135,31 @@ def test_oracle_rejects_even_k():
         oracle.count_fasta(b">a\nACGT\n", 4)
     with pytest.raises(AssertionError):
         pyoracle.count_fasta(b">a\nACGT\n", 4)
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8, 61])
+def test_all_cores_port_equals_scalar_port(threads):
+    """oracle/kmer_oracle_mt.c (bench.py's all-cores CPU leg) against pko_count_fasta: any number of threads,
+    splits landing next to headers, N runs, CRLF, lone \\r, text before the first header."""
+    import synth
+    cases = {
+        "c2": synth.c2(2_000_000)[0], "c1": synth.c1(1_000_000)[0],
+        "crlf": synth.generate(5, 300_000, 3, crlf=True, pm_ngap=20)[0],
+        "many_records": synth.generate(6, 200_000, 400)[0],
+        "preamble": np.frombuffer(b"ACGTACGTAC\nACGT\n>r1\nACGTTGCA\nAC\n>r2 x y\nNNACGTACGTA\n", dtype=np.uint8),
+        "lone_cr": np.frombuffer(b">h\nAC\rGT\rACGTAC\n\n\nACGTTT", dtype=np.uint8),
+        "empty": np.zeros(0, dtype=np.uint8),
+    }
+    for name, data in cases.items():
+        for k in (3, 7, 15):
+            if k == 15 and not (name == "c2" and threads == 8):          # 1 GiB tables: once is enough
+                continue
+            want = oracle.count_fasta(data, k)
+            got = oracle.count_fasta_mt(data, k, threads)
+            assert got is not None, name
+            assert got["num_kmers"] == want["num_kmers"] and got["total_bp"] == want["total_bp"], (name, k)
+            assert np.array_equal(got["table"], want["table"]), (name, k)
+
+
+def test_all_cores_port_declines_blanks_in_sequence_lines():
+    assert oracle.count_fasta_mt(inputs.edge_fasta(), 7, 4) is None          # interior / leading blanks: scalar port only
