@@ -223,52 +223,66 @@ __global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fa
 }
 
 // ------------------------------------------------------------------ K1: level-1 column scan -----
-// One workgroup, one thread per digit.  rowoff[w][d] = records of digit d written by rows < w;
-// bucket_base[d] = start of bucket d; level-2 rows: bucket d gets ceil(n_d / R2) workgroups.
-__global__ __launch_bounds__(1024) void k_rows1_scan(const uint32_t *__restrict__ hist_rows, uint32_t *__restrict__ rowoff, PartPlan pl,
-                                                     uint32_t *__restrict__ bucket_base, uint32_t *__restrict__ wg2_start,
-                                                     uint32_t *__restrict__ final_start) {
-    __shared__ uint32_t part[1024];                        // [P][B1] partial column sums, then their prefixes
-    __shared__ uint32_t tot[512];
-    const uint32_t B1 = pl.B1;
-    uint32_t P = 1024u / B1;                               // row groups scanned in parallel
-    if (P > 32u) P = 32u;
-    const uint32_t d = threadIdx.x % B1, g = threadIdx.x / B1;
-    const uint32_t rows_per = (pl.n_wg0 + P - 1) / P;
-    const uint32_t r_lo = g * rows_per, r_hi = min(r_lo + rows_per, pl.n_wg0);
-    const bool live = g < P;
-    uint32_t acc = 0;
-    if (live)
-        for (uint32_t w = r_lo; w < r_hi; w++) acc += hist_rows[(uint64_t)w * B1 + d];
-    if (live) part[g * B1 + d] = acc;
+// One 256-thread workgroup per digit d scans that column of the (workgroup x digit) histogram:
+// rowoff[w][d] = records of digit d written by rows < w.  The workgroup that finishes last (ticket
+// counter) turns the column totals into bucket_base[d] = start of bucket d and the level-2 work split:
+// bucket d gets ceil(n_d / R2) workgroups.
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *wsum, uint32_t &total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    __syncthreads();                                       // wsum may still be read from an earlier call
+    if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    if (g == 0) {                                          // one thread per digit: prefix over the P groups
-        uint32_t a = 0;
-        for (uint32_t q = 0; q < P; q++) { uint32_t v = part[q * B1 + d]; part[q * B1 + d] = a; a += v; }
-        tot[d] = a;
+    uint32_t pre = 0;
+    for (int i = 0; i < w; i++) pre += wsum[i];
+    total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    return pre + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_rows1_scan(const uint32_t *__restrict__ hist_rows, uint32_t *__restrict__ rowoff, PartPlan pl,
+                                                    uint32_t *col_tot, unsigned int *ticket, uint32_t *__restrict__ bucket_base,
+                                                    uint32_t *__restrict__ wg2_start, uint32_t *__restrict__ final_start) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t last;
+    const uint32_t B1 = pl.B1, d = blockIdx.x, n = pl.n_wg0;           // n <= 1024 rows: at most 4 per thread
+    const uint32_t r_lo = min(threadIdx.x * 4u, n), r_hi = min(r_lo + 4u, n);
+    uint32_t v[4], acc = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        v[j] = r_lo + j < r_hi ? hist_rows[(uint64_t)(r_lo + j) * B1 + d] : 0u;
+        acc += v[j];
     }
-    __syncthreads();
-    if (live) {
-        uint32_t a = part[g * B1 + d];
-        for (uint32_t w = r_lo; w < r_hi; w++) {
-            uint32_t v = hist_rows[(uint64_t)w * B1 + d];
-            rowoff[(uint64_t)w * B1 + d] = a;
-            a += v;
-        }
-    }
+    uint32_t total;
+    uint32_t a = block_excl_scan_256(acc, wsum, total);
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++)
+        if (r_lo + j < r_hi) { rowoff[(uint64_t)(r_lo + j) * B1 + d] = a; a += v[j]; }
     if (threadIdx.x == 0) {
-        uint32_t a = 0, wgs = 0;
-        for (uint32_t i = 0; i < B1; i++) {
-            uint32_t n = tot[i];
-            bucket_base[i] = a;
-            wg2_start[i] = wgs;
-            if (pl.b2 == 0) final_start[i] = a;
-            a += n;
-            wgs += (uint32_t)((n + pl.R2 - 1) / pl.R2);
-        }
-        bucket_base[B1] = a;
-        wg2_start[B1] = wgs;
-        if (pl.b2 == 0) final_start[B1] = a;
+        __hip_atomic_store(&col_tot[d], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == B1 - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    // the last workgroup: exclusive scans of the column totals (bucket starts) and of the per-bucket
+    // level-2 workgroup counts, two digits per thread (B1 <= 512)
+    uint32_t t0 = 0, t1 = 0;
+    const uint32_t i0 = threadIdx.x * 2u, i1 = i0 + 1u;
+    if (i0 < B1) t0 = __hip_atomic_load(&col_tot[i0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i1 < B1) t1 = __hip_atomic_load(&col_tot[i1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t g0 = (uint32_t)((t0 + pl.R2 - 1) / pl.R2), g1 = (uint32_t)((t1 + pl.R2 - 1) / pl.R2);
+    uint32_t sum_n, sum_g;
+    const uint32_t base = block_excl_scan_256(t0 + t1, wsum, sum_n);
+    const uint32_t wgs = block_excl_scan_256(g0 + g1, wsum, sum_g);
+    if (i0 < B1) { bucket_base[i0] = base; wg2_start[i0] = wgs; if (pl.b2 == 0) final_start[i0] = base; }
+    if (i1 < B1) { bucket_base[i1] = base + t0; wg2_start[i1] = wgs + g0; if (pl.b2 == 0) final_start[i1] = base + t0; }
+    if (threadIdx.x == 0) {
+        bucket_base[B1] = sum_n;
+        wg2_start[B1] = sum_g;
+        if (pl.b2 == 0) final_start[B1] = sum_n;
     }
 }
 
@@ -845,6 +859,7 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
     lay->rowoff1 = o; o += up((size_t)pl.n_wg0 * pl.B1 * 4);
     lay->bucket_base = o; o += up((size_t)(pl.B1 + 1) * 4);
     lay->wg2_start = o; o += up((size_t)(pl.B1 + 1) * 4);
+    lay->col_tot = o; o += up((size_t)(pl.B1 + 1) * 4);
     lay->final_start = o; o += up((size_t)(nfb + 1) * 4);
     lay->out1 = o; o += up((size_t)(n_bytes + 64) * (pl.b2 ? 4 : 2));
     lay->hist2 = o; o += up((size_t)pl.n_wg2_max * pl.B2 * 4);
@@ -869,7 +884,7 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     hipFuncSetAttribute((const void *)k_scatter1<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_WIDE);
     hipFuncSetAttribute((const void *)k_scatter2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_bucket_count<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (hipMemsetAsync(side_n, 0, 8, s) != hipSuccess) return -2;
+    if (hipMemsetAsync(side_n, 0, 16, s) != hipSuccess) return -2;   // side-list length + the column scan's ticket counter
     if (pl.dbg && pl.k <= 15) {                              // diagnostic build of the walk (PK_DEBUG_WALK), timing only
         hipLaunchKernelGGL((k_walk_flat<uint32_t, uint32_t, true>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, pl,
                            (uint32_t *)flat, cnt, hist1, recs, recs_cap, carry, side, side_n, lay.side_cap);
@@ -885,7 +900,8 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
         if (ev_part_end) hipEventRecord(ev_part_end, s);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
-    hipLaunchKernelGGL(k_rows1_scan, dim3(1), dim3(1024), 0, s, hist1, rowoff1, pl, bucket_base, wg2_start, final_start);
+    hipLaunchKernelGGL(k_rows1_scan, dim3(pl.B1), dim3(256), 0, s, hist1, rowoff1, pl, (uint32_t *)(ws + lay.col_tot),
+                       (unsigned int *)(side_n + 1), bucket_base, wg2_start, final_start);
     if (pl.k <= 15)
         hipLaunchKernelGGL(k_scatter1<uint32_t>, dim3(pl.n_wg0), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)flat, cnt, rowoff1,
                            bucket_base, pl, out1);
