@@ -17,17 +17,63 @@
 namespace pk {
 
 // ------------------------------------------------------------------ per-chunk summaries --------
-__global__ __launch_bounds__(WG) void k_chunk_l1(const uint8_t *__restrict__ fasta, uint64_t n_bytes, L1 *__restrict__ chunk_l1) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[WG * LDS_STRIDE];
-    __shared__ L1 sh[WG / 64];
-    uint64_t base = (uint64_t)blockIdx.x * CHUNK;
-    stage_chunk(fasta, base, n_bytes, lds);
-    __syncthreads();
-    bool dirty;
-    L1 mine = piece_l1_auto(lds, piece_len(base, n_bytes), dirty);
-    L1 total;
-    wg_excl_scan_l1(mine, 0u, sh, &total);
-    if (threadIdx.x == 0) chunk_l1[blockIdx.x] = total;
+// L1 summary of a whole chunk = (does it hold a line terminator, which line state does it end in when
+// entered at a line start).  Only the chunk's last line matters: the state after its last terminator
+// (or from its first byte, if it has none) is decided by the first non-blank byte that follows --
+// '>' opens a header, anything else sequence text.  So one wave per chunk looks at the chunk's tail,
+// 256 bytes at a time backwards to the last terminator, then forwards to the first non-blank; with
+// ordinary line lengths that is one or two loads per lane instead of a pass over the 16 KiB.
+__global__ __launch_bounds__(WG) void k_chunk_l1(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint32_t n_chunks,
+                                                 L1 *__restrict__ chunk_l1) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t chunk = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
+    if (chunk >= n_chunks) return;                                       // wave-uniform
+    const uint64_t base = (uint64_t)chunk * CHUNK;
+    const uint32_t nb = (uint32_t)(n_bytes - base < (uint64_t)CHUNK ? n_bytes - base : (uint64_t)CHUNK);
+    // the lane's 4 bytes of window w (bytes past the chunk read as 0, which is neither blank nor terminator)
+    auto window = [&](uint32_t w) -> uint32_t {
+        const uint32_t off = w * 256u + lane * 4u;
+        if (off + 4u <= nb) return *reinterpret_cast<const uint32_t *>(fasta + base + off);   // chunk bases are 16-byte aligned
+        uint32_t v = 0;
+        for (uint32_t j = 0; off + j < nb && j < 4u; j++) v |= (uint32_t)fasta[base + off + j] << (8u * j);
+        return v;
+    };
+    const uint32_t n_win = (nb + 255u) / 256u;
+    int last_term = -1;                                                  // byte index of the chunk's last terminator
+    for (int w = (int)n_win - 1; w >= 0 && last_term < 0; w--) {
+        const uint32_t v = window((uint32_t)w);
+        uint32_t tm = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) tm |= is_term((v >> (8u * j)) & 0xffu) ? (1u << j) : 0u;
+        const unsigned long long any = __ballot(tm != 0u);
+        if (any) {
+            const int hl = 63 - __builtin_clzll(any);
+            const uint32_t tmh = (uint32_t)__builtin_amdgcn_readlane((int)tm, hl);
+            last_term = w * 256 + hl * 4 + (31 - __builtin_clz(tmh));
+        }
+    }
+    const uint32_t from = (uint32_t)(last_term + 1);
+    uint32_t state = LS_START;
+    bool found = false;
+    for (uint32_t w = from / 256u; w < n_win && !found; w++) {
+        const uint32_t v = window(w);
+        uint32_t nz = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t idx = w * 256u + lane * 4u + j;
+            nz |= (idx >= from && idx < nb && !is_ws((v >> (8u * j)) & 0xffu)) ? (1u << j) : 0u;
+        }
+        const unsigned long long any = __ballot(nz != 0u);
+        if (any) {
+            const int ll = __builtin_ctzll(any);
+            const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)nz, ll);
+            const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)v, ll);
+            const uint32_t c = (word >> (8u * (uint32_t)__builtin_ctz(m))) & 0xffu;
+            state = c == '>' ? (uint32_t)LS_HEADER : (uint32_t)LS_SEQ;
+            found = true;
+        }
+    }
+    if (lane == 0) chunk_l1[chunk] = nb ? l1_make(last_term >= 0, state) : 0u;
 }
 
 __global__ __launch_bounds__(WG) void k_chunk_l2(const uint8_t *__restrict__ fasta, uint64_t n_bytes,
@@ -262,7 +308,7 @@ __global__ __launch_bounds__(WG) void k_clamp32(uint32_t *__restrict__ t, uint64
 
 // ------------------------------------------------------------------ launchers ------------------
 void launch_chunk_l1(const uint8_t *fasta, uint64_t n, L1 *chunk_l1, uint32_t n_chunks, hipStream_t s) {
-    hipLaunchKernelGGL(k_chunk_l1, dim3(n_chunks), dim3(WG), 0, s, fasta, n, chunk_l1);
+    hipLaunchKernelGGL(k_chunk_l1, dim3((n_chunks + WG / 64 - 1) / (WG / 64)), dim3(WG), 0, s, fasta, n, n_chunks, chunk_l1);
 }
 // tile_ws: scratch for ceil(n_chunks / 1024) summaries of the respective type
 void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, L1 *tile_ws, hipStream_t s) {
