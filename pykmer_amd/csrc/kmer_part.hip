@@ -301,9 +301,12 @@ constexpr size_t SCATTER_LDS_WIDE = sizeof(ScatterLds);            // 104 KiB
 
 // WIDE = the digit is kept in its own LDS array; otherwise the record parked in LDS still carries its
 // digit (digit << shift | rest fits 32 bits) and is masked on the way out.
+// `claim` != nullptr: the tile's run for digit d starts where a global cursor says (atomicAdd of the
+// run length), instead of at this workgroup's precomputed running offset L.run[d].
 template <typename RIN, bool WIDE>
 __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PER], const bool (&ok)[SC_PER], uint32_t n_tile,
-                                             uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out) {
+                                             uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out,
+                                             uint32_t *claim = nullptr) {
     uint32_t dr[SC_PER];                                   // digit (9 bits) | rank inside the tile << 9
 #pragma unroll
     for (int j = 0; j < SC_PER; j++) {
@@ -326,8 +329,10 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
         for (int i = 0; i < w; i++) pre += L.wsum[i];
         if (threadIdx.x < B) {
             L.off[threadIdx.x] = pre + inc - v;
-            L.gbase[threadIdx.x] = L.run[threadIdx.x] - (pre + inc - v);   // sorted position p of digit d goes to p + gbase[d]
-            L.run[threadIdx.x] += v;
+            uint32_t run_at;
+            if (claim) run_at = v ? atomicAdd(&claim[threadIdx.x], v) : 0u;
+            else { run_at = L.run[threadIdx.x]; L.run[threadIdx.x] += v; }
+            L.gbase[threadIdx.x] = run_at - (pre + inc - v);               // sorted position p of digit d goes to p + gbase[d]
             L.hist[threadIdx.x] = 0;                          // ready for the next tile
         }
     }
@@ -386,12 +391,18 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
 
 // level 1: source = the flat (chunk, wave) regions written by k_walk_flat; workgroup w owns the same
 // chunk range as walk workgroup w, so its row of offsets applies.
-template <typename REC0>
+// FINE: also tally, per workgroup, how many records go to every FINAL bucket (top b1+b2 address bits, at
+// most 2^14 of them: 64 KiB of LDS counters behind the tile) and write that row out; summed over the
+// workgroups it gives the final bucket sizes, so level 2 needs no counting pass over the records.
+template <typename REC0, bool FINE>
 __global__ __launch_bounds__(SC_T) void k_scatter1(const REC0 *__restrict__ flat, const uint32_t *__restrict__ cnt,
                                                    const uint32_t *__restrict__ rowoff, const uint32_t *__restrict__ bucket_base,
-                                                   PartPlan pl, void *__restrict__ out) {
+                                                   PartPlan pl, void *__restrict__ out, uint32_t *__restrict__ fine_rows) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     ScatterLds &L = *reinterpret_cast<ScatterLds *>(smem);
+    uint32_t *fine = reinterpret_cast<uint32_t *>(smem + SCATTER_LDS_NARROW);      // [B1 * B2], FINE only
+    const uint32_t n_fine = pl.B1 * pl.B2;
+    if (FINE) for (uint32_t i = threadIdx.x; i < n_fine; i += SC_T) fine[i] = 0u;
     const uint32_t B = pl.B1, shift = pl.addr_bits - pl.b1;
     const uint32_t low_mask = shift >= 32 ? 0xffffffffu : ((1u << shift) - 1u);
     const bool out16 = pl.b2 == 0;
@@ -447,8 +458,49 @@ __global__ __launch_bounds__(SC_T) void k_scatter1(const REC0 *__restrict__ flat
         bool ok[SC_PER];
 #pragma unroll
         for (int j = 0; j < SC_PER; j++) ok[j] = threadIdx.x * 4u + (j & 3) < t.n[j >> 2];
+        if (FINE) {
+#pragma unroll
+            for (int j = 0; j < SC_PER; j++)
+                if (ok[j]) atomicAdd(&fine[(uint32_t)((uint64_t)r[j] >> pl.fb_bits)], 1u);
+        }
         scatter_tile<REC0, sizeof(REC0) == 8>(L, r, ok, t.total, shift, B, low_mask, out16, out);
     }
+    if (FINE) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_fine; i += SC_T) fine_rows[(uint64_t)blockIdx.x * n_fine + i] = fine[i];
+    }
+}
+
+// column sums of the per-workgroup final-bucket tallies: grid (n_fine / 256, row groups)
+__global__ __launch_bounds__(256) void k_fine_sum(const uint32_t *__restrict__ fine_rows, uint32_t n_rows, uint32_t n_fine,
+                                                  uint32_t *__restrict__ fine_tot) {
+    const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+    if (col >= n_fine) return;
+    const uint32_t per = (n_rows + gridDim.y - 1) / gridDim.y;
+    const uint32_t r_lo = blockIdx.y * per, r_hi = min(r_lo + per, n_rows);
+    uint32_t acc = 0;
+    for (uint32_t r = r_lo; r < r_hi; r++) acc += fine_rows[(uint64_t)r * n_fine + col];
+    if (acc) atomicAdd(&fine_tot[col], acc);
+}
+
+// exclusive scan of the final bucket sizes -> final_start[0 .. n_fine] and the write cursors level 2 claims from
+__global__ __launch_bounds__(1024) void k_fine_scan(const uint32_t *__restrict__ fine_tot, uint32_t n_fine,
+                                                    uint32_t *__restrict__ final_start, uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t per = (n_fine + 1023u) / 1024u;                       // <= 16
+    const uint32_t lo = min(threadIdx.x * per, n_fine), hi = min(lo + per, n_fine);
+    uint32_t acc = 0;
+    for (uint32_t i = lo; i < hi; i++) acc += fine_tot[i];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = acc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t a = inc - acc;
+    for (int i = 0; i < w; i++) a += wsum[i];
+    for (uint32_t i = lo; i < hi; i++) { final_start[i] = a; cursor[i] = a; a += fine_tot[i]; }
+    if (threadIdx.x == 1023) final_start[n_fine] = a;
 }
 
 // level-2 work split: bucket b is covered by workgroups wg2_start[b] .. wg2_start[b+1]-1, R2 records each
@@ -510,9 +562,13 @@ __global__ __launch_bounds__(512) void k_rows2_scan(const uint32_t *__restrict__
     }
 }
 
+// CLAIM: no precomputed offsets; every tile claims room for its runs from the final buckets' cursors.  Where a
+// record lands inside its final bucket then depends on timing -- the bucket's contents as a multiset do not.
+template <bool CLAIM>
 __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ wg2_start,
                                                    const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ rowoff,
-                                                   const uint32_t *__restrict__ final_start, PartPlan pl, void *__restrict__ out) {
+                                                   const uint32_t *__restrict__ final_start, PartPlan pl, void *__restrict__ out,
+                                                   uint32_t *__restrict__ cursor) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     ScatterLds &L = *reinterpret_cast<ScatterLds *>(smem);
     uint32_t b, lo, hi;
@@ -521,7 +577,7 @@ __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ 
     const uint32_t low_mask = (1u << shift) - 1u;
     if (threadIdx.x < 512) { L.hist[threadIdx.x] = 0; L.run[threadIdx.x] = 0; }
     __syncthreads();
-    if (threadIdx.x < B) L.run[threadIdx.x] = final_start[(uint64_t)b * B + threadIdx.x] + rowoff[(uint64_t)blockIdx.x * B + threadIdx.x];
+    if (!CLAIM && threadIdx.x < B) L.run[threadIdx.x] = final_start[(uint64_t)b * B + threadIdx.x] + rowoff[(uint64_t)blockIdx.x * B + threadIdx.x];
     __syncthreads();
     // 16-byte aligned windows of TILE records over [lo, hi); the first / last window are partly masked.
     // The next window's loads are issued before the current tile is sorted, so they fly during its barriers.
@@ -549,7 +605,7 @@ __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ 
             for (int e = 0; e < 4; e++) { ok[j * 4 + e] = i + e >= v_lo && i + e < v_hi; r[j * 4 + e] = q[e]; }
         }
         if (win + TILE < hi) fetch(win + TILE, nxt);
-        scatter_tile<uint32_t, false>(L, r, ok, n_tile, shift, B, low_mask, true, out);
+        scatter_tile<uint32_t, false>(L, r, ok, n_tile, shift, B, low_mask, true, out, CLAIM ? cursor + (uint64_t)b * B : nullptr);
     }
 }
 
@@ -868,6 +924,10 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
     lay->side_cap = n_bytes + 16;                          // every side entry stands for >= 1 k-mer
     lay->side = o; o += up((size_t)lay->side_cap * 8);
     lay->side_n = o; o += 256;
+    const bool fine = pl.b2 && nfb <= 16384 && pl.k <= 15;             // level 2 without a counting pass (see k_scatter1)
+    lay->fine_rows = o; o += fine ? up((size_t)pl.n_wg0 * nfb * 4) : 0;
+    lay->fine_tot = o; o += fine ? up((size_t)nfb * 4) : 0;
+    lay->cursor = o; o += fine ? up((size_t)nfb * 4) : 0;
     lay->bucket_hist = o; o += up((size_t)nfb * 2 * 256 * 4);              // up to 2 workgroups per bucket
     return o;
 }
@@ -880,9 +940,14 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     uint32_t *final_start = (uint32_t *)(ws + lay.final_start), *hist2 = (uint32_t *)(ws + lay.hist2), *rowoff2 = (uint32_t *)(ws + lay.rowoff2);
     void *flat = ws + lay.flat, *out1 = ws + lay.out1, *out2 = ws + lay.out2;
     unsigned long long *side = (unsigned long long *)(ws + lay.side), *side_n = (unsigned long long *)(ws + lay.side_n);
-    hipFuncSetAttribute((const void *)k_scatter1<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
-    hipFuncSetAttribute((const void *)k_scatter1<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_WIDE);
-    hipFuncSetAttribute((const void *)k_scatter2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
+    const uint32_t nfb = pl.B1 * pl.B2;
+    const bool fine = pl.b2 && nfb <= 16384 && pl.k <= 15;
+    const size_t lds_fine = SCATTER_LDS_NARROW + (size_t)nfb * 4;
+    hipFuncSetAttribute((const void *)k_scatter1<uint32_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
+    hipFuncSetAttribute((const void *)k_scatter1<uint32_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SCATTER_LDS_NARROW + 65536));
+    hipFuncSetAttribute((const void *)k_scatter1<uint64_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_WIDE);
+    hipFuncSetAttribute((const void *)k_scatter2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
+    hipFuncSetAttribute((const void *)k_scatter2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_bucket_count<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (hipMemsetAsync(side_n, 0, 16, s) != hipSuccess) return -2;   // side-list length + the column scan's ticket counter
     if (pl.dbg && pl.k <= 15) {                              // diagnostic build of the walk (PK_DEBUG_WALK), timing only
@@ -902,22 +967,33 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     }
     hipLaunchKernelGGL(k_rows1_scan, dim3(pl.B1), dim3(256), 0, s, hist1, rowoff1, pl, (uint32_t *)(ws + lay.col_tot),
                        (unsigned int *)(side_n + 1), bucket_base, wg2_start, final_start);
-    if (pl.k <= 15)
-        hipLaunchKernelGGL(k_scatter1<uint32_t>, dim3(pl.n_wg0), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)flat, cnt, rowoff1,
-                           bucket_base, pl, out1);
+    uint32_t *fine_rows = (uint32_t *)(ws + lay.fine_rows), *fine_tot = (uint32_t *)(ws + lay.fine_tot), *cursor = (uint32_t *)(ws + lay.cursor);
+    if (fine) {
+        if (hipMemsetAsync(fine_tot, 0, (size_t)nfb * 4, s) != hipSuccess) return -2;
+        hipLaunchKernelGGL((k_scatter1<uint32_t, true>), dim3(pl.n_wg0), dim3(SC_T), lds_fine, s, (const uint32_t *)flat, cnt, rowoff1,
+                           bucket_base, pl, out1, fine_rows);
+    } else if (pl.k <= 15)
+        hipLaunchKernelGGL((k_scatter1<uint32_t, false>), dim3(pl.n_wg0), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)flat, cnt, rowoff1,
+                           bucket_base, pl, out1, (uint32_t *)nullptr);
     else
-        hipLaunchKernelGGL(k_scatter1<uint64_t>, dim3(pl.n_wg0), dim3(SC_T), SCATTER_LDS_WIDE, s, (const uint64_t *)flat, cnt, rowoff1,
-                           bucket_base, pl, out1);
+        hipLaunchKernelGGL((k_scatter1<uint64_t, false>), dim3(pl.n_wg0), dim3(SC_T), SCATTER_LDS_WIDE, s, (const uint64_t *)flat, cnt, rowoff1,
+                           bucket_base, pl, out1, (uint32_t *)nullptr);
     const uint16_t *final_recs = (const uint16_t *)out1;
-    if (pl.b2) {
+    if (fine) {
+        const uint32_t row_groups = pl.n_wg0 < 16u ? 1u : 16u;
+        hipLaunchKernelGGL(k_fine_sum, dim3((nfb + 255u) / 256u, row_groups), dim3(256), 0, s, (const uint32_t *)fine_rows, pl.n_wg0, nfb, fine_tot);
+        hipLaunchKernelGGL(k_fine_scan, dim3(1), dim3(1024), 0, s, (const uint32_t *)fine_tot, nfb, final_start, cursor);
+        hipLaunchKernelGGL(k_scatter2<true>, dim3(pl.n_wg2_max), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
+                           bucket_base, (const uint32_t *)nullptr, final_start, pl, out2, cursor);
+        final_recs = (const uint16_t *)out2;
+    } else if (pl.b2) {
         hipLaunchKernelGGL(k_count2, dim3(pl.n_wg2_max), dim3(WG), 0, s, (const uint32_t *)out1, wg2_start, bucket_base, pl, hist2);
         hipLaunchKernelGGL(k_rows2_scan, dim3(pl.B1), dim3(512), 0, s, hist2, rowoff2, wg2_start, bucket_base, pl, final_start);
-        hipLaunchKernelGGL(k_scatter2, dim3(pl.n_wg2_max), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
-                           bucket_base, rowoff2, final_start, pl, out2);
+        hipLaunchKernelGGL(k_scatter2<false>, dim3(pl.n_wg2_max), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
+                           bucket_base, rowoff2, final_start, pl, out2, (uint32_t *)nullptr);
         final_recs = (const uint16_t *)out2;
     }
     if (ev_part_end) hipEventRecord(ev_part_end, s);
-    const uint32_t nfb = pl.B1 * pl.B2;
     // sparse tables (few records per 2^16-address bucket, k=17): 2^split workgroups per bucket, see k_bucket_count
     const uint32_t split = (pl.fb_bits == 16 && n / nfb < 8192) ? 1u : 0u;
     const size_t part_addrs = (size_t)1 << (pl.fb_bits - split);

@@ -48,7 +48,7 @@ struct PartPlan {
     uint32_t dbg;            // PK_DEBUG_WALK ablation bits (timing diagnostics only; 0 in production)
 };
 struct PartWorkspace {       // byte offsets into one device allocation
-    size_t flat, cnt, hist1, rowoff1, bucket_base, wg2_start, col_tot, final_start, out1, hist2, rowoff2, out2, side, side_n, bucket_hist;
+    size_t flat, cnt, hist1, rowoff1, bucket_base, wg2_start, col_tot, final_start, out1, hist2, rowoff2, out2, side, side_n, bucket_hist, fine_rows, fine_tot, cursor;
     uint64_t side_cap;
 };
 PartPlan make_part_plan(uint32_t k, uint64_t n_bytes);
