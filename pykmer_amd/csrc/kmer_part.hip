@@ -9,17 +9,22 @@
 //                    fixed per-(chunk,wave) regions of a flat record array; per-workgroup histogram
 //                    of the level-1 digit (top b1 address bits)
 //   K1 k_rows1_scan  column scan of those histograms -> exact output offset of every (workgroup, digit)
-//   K2 k_scatter     LDS counting sort of each 16K-record tile by digit, coalesced run writes
-//   K3 k_count2      per-workgroup histogram of the level-2 digit (next b2 bits) inside each level-1 bucket
-//   K4 k_rows2_scan  per-bucket column scan -> offsets + start of every final bucket
-//   K5 k_scatter     second pass, 16-bit records (address inside the final bucket)
+//   K2 k_scatter1    LDS counting sort of each 16K-record tile by digit, coalesced run writes; for
+//                    k <= 15 it also tallies the size of every FINAL bucket (2^14 LDS counters per workgroup)
+//   K3 k_fine_sum / k_fine_scan  (k <= 15) final bucket starts + write cursors from those tallies
+//      k_count2 / k_rows2_scan   (k = 17)  per-workgroup histogram of the level-2 digit (next b2 bits)
+//                    inside each level-1 bucket, per-bucket column scan -> offsets + final bucket starts
+//   K5 k_scatter2    second pass, 16-bit records (address inside the final bucket).  k <= 15: every tile
+//                    claims room for its runs from the cursors (atomicAdd), there is no counting pass
 //   K6 k_bucket_count one workgroup per final bucket of 2^16 addresses: the slice of the u8 table
-//                    lives in LDS as 16-bit counters, ds_add per record, clamp, one coalesced
-//                    read-modify-write of the slice in HBM
+//                    lives in LDS as 16-bit counters, ds_add per record, clamp, slice written to HBM
+//                    (read back first when an earlier feed already wrote it)
+//   K7 k_apply_side  the few hot k-mers the walk kept out of the record stream (below)
 //
-// Every pass is a stream: FASTA 0.8 GB + records 3.1+3.1+3.1+3.1+1.5+1.5 GB + table 2x1 GiB at
-// k=15 / 800 Mbp.  Offsets come from histograms + scans, so no pass needs a global atomic and the
-// record order (hence the result) is deterministic.  Saturation is exact: min(255, .) is applied
+// Every pass is a stream: FASTA 0.8 GB + records 2.8+3.3+3.0+2.7+1.6+1.3 GB + table 1 GiB at
+// k=15 / 800 Mbp.  Bucket boundaries come from histograms + scans, so no pass needs a global atomic
+// per record.  With claimed runs the order of records inside a final bucket depends on timing; the
+// table -- a saturating sum per address -- does not.  Saturation is exact: min(255, .) is applied
 // only when a bucket's counters leave LDS (indexer.py:239,262), and K6 folds the slice already in
 // HBM back in, so several feeds accumulate exactly like the reference's flushes.
 #include <cstddef>
