@@ -323,6 +323,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
     }
     __syncthreads();
     // exclusive scan of hist[0..B) by the first B threads (B <= 512 <= SC_T)
+    uint32_t my_off = 0, claimed = 0;
     {
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         uint32_t v = threadIdx.x < B ? L.hist[threadIdx.x] : 0u, inc = v;
@@ -332,12 +333,13 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
         __syncthreads();
         uint32_t pre = 0;
         for (int i = 0; i < w; i++) pre += L.wsum[i];
+        my_off = pre + inc - v;
         if (threadIdx.x < B) {
-            L.off[threadIdx.x] = pre + inc - v;
-            uint32_t run_at;
-            if (claim) run_at = v ? atomicAdd(&claim[threadIdx.x], v) : 0u;
-            else { run_at = L.run[threadIdx.x]; L.run[threadIdx.x] += v; }
-            L.gbase[threadIdx.x] = run_at - (pre + inc - v);               // sorted position p of digit d goes to p + gbase[d]
+            L.off[threadIdx.x] = my_off;
+            // a claimed run start is only needed when the runs are written: the atomic's round trip to HBM
+            // overlaps the parking of the records below
+            if (claim) claimed = v ? atomicAdd(&claim[threadIdx.x], v) : 0u;
+            else { L.gbase[threadIdx.x] = L.run[threadIdx.x] - my_off; L.run[threadIdx.x] += v; }
             L.hist[threadIdx.x] = 0;                          // ready for the next tile
         }
     }
@@ -350,6 +352,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
             if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)dg; }
             else L.rec[p] = (uint32_t)r[j];
         }
+    if (claim && threadIdx.x < B) L.gbase[threadIdx.x] = claimed - my_off;   // sorted position p of digit d goes to p + gbase[d]
     __syncthreads();
     if (out16) {
         // 16-bit records: each thread takes pairs of neighbours in sorted order and writes them as one
