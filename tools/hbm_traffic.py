@@ -16,7 +16,7 @@ import re
 import sys
 
 PIPELINE = ("k_chunk_l1", "k_chunk_l2", "k_scan_l1_reduce", "k_scan_l1_tiles", "k_scan_l1_apply", "k_scan_l2_reduce",
-            "k_scan_l2_tiles", "k_scan_l2_apply", "k_walk_flat", "k_rows1_scan", "k_scatter1", "k_count2", "k_rows2_scan",
+            "k_scan_l2_tiles", "k_scan_l2_apply", "k_walk_flat", "k_rows1_scan", "k_scatter1", "k_fine_sum", "k_fine_scan", "k_count2", "k_rows2_scan",
             "k_scatter2", "k_bucket_count", "k_hist_reduce", "k_apply_side")
 
 
