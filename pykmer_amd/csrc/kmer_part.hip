@@ -308,10 +308,17 @@ constexpr size_t SCATTER_LDS_WIDE = sizeof(ScatterLds);            // 104 KiB
 // digit (digit << shift | rest fits 32 bits) and is masked on the way out.
 // `claim` != nullptr: the tile's run for digit d starts where a global cursor says (atomicAdd of the
 // run length), instead of at this workgroup's precomputed running offset L.run[d].
-template <typename RIN, bool WIDE>
+//
+// `settle()` is called once the tile is parked, right before its runs are stored.  The callers use it to
+// take delivery of the NEXT tile's prefetched records at that point.  On this ISA loads and stores share one
+// in-order counter (vmcnt): a wait placed after the stores -- where the compiler would put it, at the top
+// of the next tile -- also waits for the stores to be acknowledged by HBM, a full round trip of ~8 us per
+// tile with nothing else in flight.  Waiting here costs nothing (the loads were issued a whole sort ago)
+// and leaves the stores in flight through the next tile's ranking and parking.
+template <typename RIN, bool WIDE, class Settle>
 __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PER], const bool (&ok)[SC_PER], uint32_t n_tile,
                                              uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out,
-                                             uint32_t *claim = nullptr) {
+                                             Settle &&settle, uint32_t *claim = nullptr) {
     uint32_t dr[SC_PER];                                   // digit (9 bits) | rank inside the tile << 9
 #pragma unroll
     for (int j = 0; j < SC_PER; j++) {
@@ -354,6 +361,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
         }
     if (claim && threadIdx.x < B) L.gbase[threadIdx.x] = claimed - my_off;   // sorted position p of digit d goes to p + gbase[d]
     __syncthreads();
+    settle();
     if (out16) {
         // 16-bit records: each thread takes pairs of neighbours in sorted order and writes them as one
         // dword when they fall in the same run and the destination is even (the common case)
@@ -424,54 +432,42 @@ __global__ __launch_bounds__(SC_T) void k_scatter1(const REC0 *__restrict__ flat
     // n[s] are allocated but hold no record -- they are read anyway and masked, which keeps the loads
     // branch-free.
     static_assert(SUB == 4 * SC_T && SC_PER == 16, "tile layout");
-    struct TileMeta { uint32_t n[4], total; };
-    auto meta = [&](uint32_t c) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(cnt + (uint64_t)c * 4);
-        TileMeta t;
-        t.n[0] = v.x; t.n[1] = v.y; t.n[2] = v.z; t.n[3] = v.w;
-        t.total = v.x + v.y + v.z + v.w;
-        return t;
-    };
-    struct alignas(sizeof(REC0) * 4) Quad { REC0 v[4]; };
-    auto fetch = [&](uint32_t c, REC0 (&r)[SC_PER]) {
+    typedef uint32_t Counts __attribute__((ext_vector_type(4)));         // records in the chunk's four regions
+    auto meta = [&](uint32_t c) { return *reinterpret_cast<const Counts *>(cnt + (uint64_t)c * 4); };
+    typedef REC0 Quad __attribute__((ext_vector_type(4)));               // one load, one register tuple, one asm operand
+    auto fetch = [&](uint32_t c, Quad (&q)[4]) {
         const Quad *src = reinterpret_cast<const Quad *>(flat + (uint64_t)c * 4 * SUB) + threadIdx.x;
 #pragma unroll
-        for (int sreg = 0; sreg < 4; sreg++) {
-            const Quad q = src[sreg * (SUB / 4)];
-#pragma unroll
-            for (int e = 0; e < 4; e++) r[sreg * 4 + e] = q.v[e];
-        }
+        for (int sreg = 0; sreg < 4; sreg++) q[sreg] = src[sreg * (SUB / 4)];
     };
-    // 32-bit records: the next chunk's loads are issued before the current tile is sorted, so they fly
-    // during its barriers (64-bit records would not fit the register budget twice)
-    constexpr bool AHEAD = true;
-    REC0 nxt[AHEAD ? SC_PER : 1];
-    TileMeta tn = {{0, 0, 0, 0}, 0};
-    if constexpr (AHEAD) {
-        if (c_lo < c_hi) { tn = meta(c_lo); fetch(c_lo, nxt); }
-    }
+    // The next chunk's loads are issued before the current tile is sorted, so they fly during its barriers;
+    // settle() (see scatter_tile) takes delivery of them before the current tile's stores are issued.  The
+    // empty asm makes the registers "defined here" for the compiler, so it adds no wait of its own later.
+    Quad nxt[4] = {};
+    Counts nxt_n = {0u, 0u, 0u, 0u};
+    auto settle = [&]() {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0); lgkmcnt / expcnt untouched
+        asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt_n));
+    };
+    if (c_lo < c_hi) { nxt_n = meta(c_lo); fetch(c_lo, nxt); }
+    settle();
     for (uint32_t c = c_lo; c < c_hi; c++) {
         REC0 r[SC_PER];
-        TileMeta t;
-        if constexpr (AHEAD) {
-            t = tn;
+        const uint32_t tile_n[4] = {nxt_n.x, nxt_n.y, nxt_n.z, nxt_n.w};
+        const uint32_t tile_total = tile_n[0] + tile_n[1] + tile_n[2] + tile_n[3];
 #pragma unroll
-            for (int j = 0; j < SC_PER; j++) r[j] = nxt[j];
-            if (c + 1 < c_hi) { tn = meta(c + 1); fetch(c + 1, nxt); }
-        } else {
-            t = meta(c);
-            if (t.total) fetch(c, r);
-        }
-        if (t.total == 0) continue;
+        for (int j = 0; j < SC_PER; j++) r[j] = nxt[j >> 2][j & 3];
+        if (c + 1 < c_hi) { nxt_n = meta(c + 1); fetch(c + 1, nxt); }
+        if (tile_total == 0) { settle(); continue; }
         bool ok[SC_PER];
 #pragma unroll
-        for (int j = 0; j < SC_PER; j++) ok[j] = threadIdx.x * 4u + (j & 3) < t.n[j >> 2];
+        for (int j = 0; j < SC_PER; j++) ok[j] = threadIdx.x * 4u + (j & 3) < tile_n[j >> 2];
         if (FINE) {
 #pragma unroll
             for (int j = 0; j < SC_PER; j++)
                 if (ok[j]) atomicAdd(&fine[(uint32_t)((uint64_t)r[j] >> pl.fb_bits)], 1u);
         }
-        scatter_tile<REC0, sizeof(REC0) == 8>(L, r, ok, t.total, shift, B, low_mask, out16, out);
+        scatter_tile<REC0, sizeof(REC0) == 8>(L, r, ok, tile_total, shift, B, low_mask, out16, out, settle);
     }
     if (FINE) {
         __syncthreads();
@@ -589,17 +585,23 @@ __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ 
     __syncthreads();
     // 16-byte aligned windows of TILE records over [lo, hi); the first / last window are partly masked.
     // The next window's loads are issued before the current tile is sorted, so they fly during its barriers.
-    auto fetch = [&](uint32_t win, uint4 (&v)[SC_PER / 4]) {
+    typedef uint32_t Quad __attribute__((ext_vector_type(4)));
+    auto fetch = [&](uint32_t win, Quad (&v)[SC_PER / 4]) {
         const uint32_t v_hi = min(hi, win + (uint32_t)TILE);
 #pragma unroll
         for (int j = 0; j < SC_PER / 4; j++) {
             const uint32_t i = win + (threadIdx.x + j * SC_T) * 4u;
-            v[j] = make_uint4(0, 0, 0, 0);
-            if (i < v_hi) v[j] = *reinterpret_cast<const uint4 *>(in + i);
+            v[j] = Quad{0u, 0u, 0u, 0u};
+            if (i < v_hi) v[j] = *reinterpret_cast<const Quad *>(in + i);
         }
     };
-    uint4 nxt[SC_PER / 4];
+    Quad nxt[SC_PER / 4];
+    auto settle = [&]() {                                                // see scatter_tile / k_scatter1
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
+    };
     fetch(lo & ~3u, nxt);
+    settle();
     for (uint32_t win = lo & ~3u; win < hi; win += TILE) {
         const uint32_t v_lo = max(lo, win), v_hi = min(hi, win + (uint32_t)TILE);
         const uint32_t n_tile = v_hi - v_lo;
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ 
             for (int e = 0; e < 4; e++) { ok[j * 4 + e] = i + e >= v_lo && i + e < v_hi; r[j * 4 + e] = q[e]; }
         }
         if (win + TILE < hi) fetch(win + TILE, nxt);
-        scatter_tile<uint32_t, false>(L, r, ok, n_tile, shift, B, low_mask, true, out, CLAIM ? cursor + (uint64_t)b * B : nullptr);
+        scatter_tile<uint32_t, false>(L, r, ok, n_tile, shift, B, low_mask, true, out, settle, CLAIM ? cursor + (uint64_t)b * B : nullptr);
     }
 }
 
