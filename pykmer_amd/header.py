@@ -258,15 +258,18 @@ class Header(HeaderVars):
         for fhd in self.open_index_tmp_file():
             self.update_stats(fhd)
 
-    def update_metadata(self, index_file: str) -> None:
-        """tools.py:273-291."""
+    def update_metadata(self, index_file: str, checksums=None) -> None:
+        """tools.py:273-291.  `checksums` = {"input": hex, "output": hex} when the caller already hashed the
+        very bytes of the two files (the indexer does, in threads, while the GPU counts and the table is
+        written); otherwise both files are read back and hashed here, as the reference does."""
         print("updating metadata")
+        checksums = checksums or {}
         self.input_file_size = os.path.getsize(self.input_file_path)
         self.input_file_ctime = os.path.getctime(self.input_file_path)
-        self.input_file_cheksum = gen_checksum(self.input_file_path)
+        self.input_file_cheksum = checksums.get("input") or gen_checksum(self.input_file_path)
         self.output_file_size = os.path.getsize(index_file)
         self.output_file_ctime = os.path.getctime(index_file)
-        self.output_file_cheksum = gen_checksum(index_file)
+        self.output_file_cheksum = checksums.get("output") or gen_checksum(index_file)
         self.hostname = socket.gethostname()
         # the reference hashes `tools.py` found in the cwd (tools.py:285); this build hashes its own format module
         self.checksum_script = gen_checksum(os.path.abspath(__file__))
@@ -341,10 +344,10 @@ class Header(HeaderVars):
             return self.get_array_from_fhd(fhd, mode=mm_mode)
 
     # ---- metadata (tools.py:366-401)
-    def write_metadata_file(self, index_file: str, hist256=None) -> None:
+    def write_metadata_file(self, index_file: str, hist256=None, checksums=None) -> None:
         assert self.num_kmers
         assert self.chromosomes
-        self.update_metadata(index_file)
+        self.update_metadata(index_file, checksums=checksums)
         if hist256 is not None:                               # histogram already built in HBM by the indexer
             self.update_stats_from_hist256(hist256)
         else:
@@ -356,8 +359,8 @@ class Header(HeaderVars):
     def write_metadata_index_file(self, hist256=None) -> None:
         self.write_metadata_file(self.index_file, hist256=hist256)
 
-    def write_metadata_index_tmp_file(self, hist256=None) -> None:
-        self.write_metadata_file(self.index_tmp_file, hist256=hist256)
+    def write_metadata_index_tmp_file(self, hist256=None, checksums=None) -> None:
+        self.write_metadata_file(self.index_tmp_file, hist256=hist256, checksums=checksums)
 
     def read_metadata(self) -> None:
         with open(self.metadata_file, "rt") as fhd:

@@ -12,7 +12,7 @@ from typing import List, Union
 import numpy as np
 
 from . import _lib
-from .header import Header
+from .header import Header, gen_checksum
 
 FEED_BYTES = 1 << 30            # host -> device staging granularity
 RESIDENT_LIMIT = 16 << 30       # inputs up to this size (decompressed) are kept in host memory for the header names
@@ -116,6 +116,12 @@ def create_fasta_index(
           f"{header.max_size // 1024 // 1024:15,d} Mb {header.max_size // 1024 // 1024 // 1024:15,d} Gb")
     header._init_clean(overwrite=overwrite)                    # indexer.py:327 (the sparse tmp file is written whole below)
 
+    # the two sha256 sums of the .kin.json (tools.py:280,283) run beside the work instead of after it: the input
+    # file is hashed while the GPU counts, the table while it is written (hashlib releases the GIL)
+    import concurrent.futures
+    import hashlib
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=2)
+    input_sum = pool.submit(gen_checksum, header.input_file_path, 1 << 22)
     table, fin, everything = count_file(input_file, kmer_len, device=device)
     for num, (name, seq_len, n_valid) in enumerate(everything):
         print(f"{num + 1:03d} {name} {seq_len:15,d}")           # indexer.py:136
@@ -126,10 +132,13 @@ def create_fasta_index(
     print(f"project_name {header.project_name} kmer_len {header.kmer_len:15,d} num_kmers {header.num_kmers:15,d} "
           f"kmer_size {header.kmer_size:15,d} max_size {header.max_size:15,d}")
 
+    table_sum = pool.submit(lambda: hashlib.sha256(memoryview(table)).hexdigest())
     with open(header.index_tmp_file, "wb") as fh:              # tools.py:333-341: exactly 4^k bytes, no header
         table.tofile(fh)
     print("  indexing finished. creating header")
-    header.write_metadata_index_tmp_file(hist256=fin["hist256"])   # asserts num_kmers and chromosomes (tools.py:367-368)
+    checksums = {"input": input_sum.result(), "output": table_sum.result()}
+    pool.shutdown()
+    header.write_metadata_index_tmp_file(hist256=fin["hist256"], checksums=checksums)   # asserts num_kmers and chromosomes (tools.py:367-368)
     print("renaming")
     os.rename(header.index_tmp_file, header.index_file_root)  # indexer.py:412
     print("done")
