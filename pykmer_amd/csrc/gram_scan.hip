@@ -11,9 +11,10 @@
 // The kernel is HBM-bound (N * 4^k bytes); MFMA is deliberately not used.
 //
 // Two shapes:
-//   k_gram_reg<NT>  N <= 16: all N masks and all N(N+1)/2 accumulators in registers, no LDS, no barrier
-//   k_gram_blk      any N <= 128: masks of a 256-word tile staged in LDS, 8x8 table "pair blocks"
-//                   spread over the waves of the workgroup, accumulators (2-3 x 64) in registers
+//   k_gram_reg<NT>  N <= 8: all N masks and all N(N+1)/2 accumulators in registers, no LDS, no barrier
+//   k_gram_blk      9 <= N <= 128: masks of a 256-word tile staged in LDS, 8x8 table "pair blocks"
+//                   spread over the waves of the workgroup, accumulators (1-3 x 64) in registers.
+//                   Measured faster than the register shape from two blocks on (N=13: 6.2 vs 5.1 TB/s)
 #include "pk_kernels.h"
 
 namespace pk {
@@ -58,21 +59,27 @@ __device__ __forceinline__ uint32_t mask32(const uint4 &a, const uint4 &b, const
     return m;
 }
 
-// guarded load of 32 bytes starting at word w (bytes beyond n read as 0 = never valid)
-__device__ __forceinline__ void load_word(const uint8_t *t, uint64_t w, uint64_t n, uint4 &a, uint4 &b) {
-    uint64_t off = w * 32u;
-    if (off + 32u <= n) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(t + off);
+// The 32 addresses of "word" w.  Words are numbered so that the 64 lanes of a wave (64 consecutive words)
+// cover one 2 KiB block with two fully contiguous 1 KiB load instructions: lane l of block B takes bytes
+// [B*2048 + l*16, +16) and [B*2048 + 1024 + l*16, +16).  Which 32 addresses share a word does not matter to
+// the tallies as long as every table uses the same grouping.  Bytes at or beyond n read as 0 (never valid).
+__device__ __forceinline__ uint64_t n_words_for(uint64_t n) { return ((n + 2047u) / 2048u) * 64u; }
+
+__device__ __forceinline__ uint4 load_half(const uint8_t *t, uint64_t off, uint64_t n) {
+    if (off + 16u <= n) {
         // every byte is read exactly once: stream it past the caches (nontemporal)
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 *q = reinterpret_cast<const u32x4 *>(p);
-        const u32x4 x = __builtin_nontemporal_load(q), y = __builtin_nontemporal_load(q + 1);
-        a = make_uint4(x.x, x.y, x.z, x.w); b = make_uint4(y.x, y.y, y.z, y.w);
-    } else {
-        uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint64_t i = off; i < n; i++) v[(i - off) >> 2] |= (uint32_t)t[i] << (8u * ((i - off) & 3u));
-        a = make_uint4(v[0], v[1], v[2], v[3]); b = make_uint4(v[4], v[5], v[6], v[7]);
+        const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(t + off));
+        return make_uint4(x.x, x.y, x.z, x.w);
     }
+    uint32_t v[4] = {0, 0, 0, 0};
+    for (uint64_t i = off; i < n; i++) v[(i - off) >> 2] |= (uint32_t)t[i] << (8u * ((i - off) & 3u));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void load_word(const uint8_t *t, uint64_t w, uint64_t n, uint4 &a, uint4 &b) {
+    const uint64_t off = (w >> 6) * 2048u + (w & 63u) * 16u;
+    a = load_half(t, off, n);
+    b = load_half(t, off + 1024u, n);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -81,7 +88,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-// ------------------------------------------------------------------ N <= 16: registers only ----
+// ------------------------------------------------------------------ N <= 8: registers only -----
 template <int NT, bool FAST>
 __global__ __launch_bounds__(256) void k_gram_reg(const uint8_t *const *__restrict__ tables, uint64_t n, ValidParams vp,
                                                   unsigned long long *__restrict__ pair) {
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(256) void k_gram_reg(const uint8_t *const *__restri
     uint32_t acc[NT * (NT + 1) / 2];
 #pragma unroll
     for (int i = 0; i < NT * (NT + 1) / 2; i++) acc[i] = 0;
-    const uint64_t n_words = (n + 31u) / 32u;
+    const uint64_t n_words = n_words_for(n);
     for (uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * 256u) {
         uint32_t m[NT];
 #pragma unroll
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(MAXT) void k_gram_blk(const uint8_t *const *__restr
 #pragma unroll
             for (int j = 0; j < BLK; j++) acc[s][i][j] = 0;
 
-    const uint64_t n_words = (n + 31u) / 32u;
+    const uint64_t n_words = n_words_for(n);
     const uint64_t n_tiles = (n_words + TILE_WORDS - 1) / TILE_WORDS;
     const int items = NB * BLK * TILE_WORDS;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -233,14 +240,13 @@ int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int m
     vp.up_rep = (uint32_t)((max_count + 1) & 0x7f) * 0x01010101u;
     vp.up_hi = (max_count + 1) >= 128;
     const bool fast = (min_count == 1 && max_count == 255);
-    const uint64_t n_words = (n_slice + 31u) / 32u;
-    if (N <= 16) {
+    const uint64_t n_words = ((n_slice + 2047u) / 2048u) * 64u;          // n_words_for(n_slice)
+    if (N <= 8) {                                         // one 8-table block: registers only
         uint64_t g = (n_words + 255u) / 256u;
         uint32_t grid = (uint32_t)(g < 256u * 8u ? g : 256u * 8u);
         switch (N) {
 #define PK_CASE(X) case X: launch_reg<X>(dev_tables, n_slice, vp, fast, dev_pair, grid, s); break;
             PK_CASE(1) PK_CASE(2) PK_CASE(3) PK_CASE(4) PK_CASE(5) PK_CASE(6) PK_CASE(7) PK_CASE(8)
-            PK_CASE(9) PK_CASE(10) PK_CASE(11) PK_CASE(12) PK_CASE(13) PK_CASE(14) PK_CASE(15) PK_CASE(16)
 #undef PK_CASE
         }
     } else {
@@ -254,9 +260,9 @@ int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int m
         pbs.n = 0;
         auto flush = [&]() {
             if (!pbs.n) return;
-            // accumulators per lane: 64 / 128 / 192.  Measured at k=15: 6 blocks (N 17-24) 5.5 TB/s with 2 slots
-            // (3 waves, several workgroups per CU) vs 4.6 with 1; 10 blocks (N 25-32) 5.1 TB/s with 1 slot vs 4.2 with 2
-            const int slots = pbs.n <= 6 ? 2 : pbs.n <= 12 ? 1 : pbs.n <= 16 ? 2 : 3;
+            // accumulators per lane: 64 / 128 / 192.  Measured at k=15 (TB/s, 1 slot vs 2): 3 blocks N=13 5.9 vs 5.8,
+            // N=16 5.6 vs 5.9 (the register kernel: 5.1 / 4.7); 6 blocks N=24 4.9 vs 5.1; 10 blocks N=32 5.9 vs 4.2
+            const int slots = pbs.n <= 3 ? (N <= 14 ? 1 : 2) : pbs.n <= 6 ? 2 : pbs.n <= 12 ? 1 : pbs.n <= 16 ? 2 : 3;
             const int waves = (pbs.n + slots - 1) / slots;
             if (lds > 64u * 1024u) {                       // opt in to more than 64 KiB of dynamic LDS
                 hipFuncSetAttribute((const void *)k_gram_blk<1, true, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
