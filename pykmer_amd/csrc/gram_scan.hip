@@ -10,11 +10,9 @@
 //   pair[i][j] = sum popc(m_i & m_j)    = shared_ij (tools.py:475,482)
 // The kernel is HBM-bound (N * 4^k bytes); MFMA is deliberately not used.
 //
-// Two shapes:
-//   k_gram_reg<NT>  N <= 8: all N masks and all N(N+1)/2 accumulators in registers, no LDS, no barrier
-//   k_gram_blk      9 <= N <= 128: masks of a 256-word tile staged in LDS, 8x8 table "pair blocks"
+//   k_gram_blk      N <= 128: masks of a 256-word tile staged in LDS, 8x8 table "pair blocks"
 //                   spread over the waves of the workgroup, accumulators (1-3 x 64) in registers.
-//                   Measured faster than the register shape from two blocks on (N=13: 6.2 vs 5.1 TB/s)
+//                   (An all-in-registers kernel for N <= 16 was measured slower: N=13 5.1 vs 6.2 TB/s.)
 #include "pk_kernels.h"
 
 namespace pk {
@@ -86,41 +84,6 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
     return v;
-}
-
-// ------------------------------------------------------------------ N <= 8: registers only -----
-template <int NT, bool FAST>
-__global__ __launch_bounds__(256) void k_gram_reg(const uint8_t *const *__restrict__ tables, uint64_t n, ValidParams vp,
-                                                  unsigned long long *__restrict__ pair) {
-    const uint8_t *tp[NT];
-#pragma unroll
-    for (int i = 0; i < NT; i++) tp[i] = tables[i];
-    uint32_t acc[NT * (NT + 1) / 2];
-#pragma unroll
-    for (int i = 0; i < NT * (NT + 1) / 2; i++) acc[i] = 0;
-    const uint64_t n_words = n_words_for(n);
-    for (uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * 256u) {
-        uint32_t m[NT];
-#pragma unroll
-        for (int i = 0; i < NT; i++) {
-            uint4 a, b;
-            load_word(tp[i], w, n, a, b);
-            m[i] = mask32<FAST>(a, b, vp);
-        }
-        int idx = 0;
-#pragma unroll
-        for (int i = 0; i < NT; i++)
-#pragma unroll
-            for (int j = i; j < NT; j++) acc[idx++] += __builtin_popcount(m[i] & m[j]);
-    }
-    int idx = 0;
-#pragma unroll
-    for (int i = 0; i < NT; i++)
-#pragma unroll
-        for (int j = i; j < NT; j++) {
-            uint32_t s = wave_sum(acc[idx++]);
-            if ((threadIdx.x & 63) == 0 && s) atomicAdd(&pair[i * NT + j], (unsigned long long)s);
-        }
 }
 
 // ------------------------------------------------------------------ any N: LDS-tiled ------------
@@ -221,13 +184,6 @@ __global__ __launch_bounds__(MAXT) void k_gram_blk(const uint8_t *const *__restr
 }
 
 // ------------------------------------------------------------------ launcher --------------------
-template <int NT>
-static void launch_reg(const uint8_t *const *t, uint64_t n, const ValidParams &vp, bool fast, unsigned long long *pair, uint32_t grid,
-                       hipStream_t s) {
-    if (fast) hipLaunchKernelGGL((k_gram_reg<NT, true>), dim3(grid), dim3(256), 0, s, t, n, vp, pair);
-    else hipLaunchKernelGGL((k_gram_reg<NT, false>), dim3(grid), dim3(256), 0, s, t, n, vp, pair);
-}
-
 int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int min_count, int max_count,
                 unsigned long long *dev_pair, hipStream_t s) {
     if (N < 1 || N > 128) return -1;                      // 128 tables x 256 words x 4 B = 128 KiB of LDS
@@ -241,15 +197,7 @@ int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int m
     vp.up_hi = (max_count + 1) >= 128;
     const bool fast = (min_count == 1 && max_count == 255);
     const uint64_t n_words = ((n_slice + 2047u) / 2048u) * 64u;          // n_words_for(n_slice)
-    if (N <= 8) {                                         // one 8-table block: registers only
-        uint64_t g = (n_words + 255u) / 256u;
-        uint32_t grid = (uint32_t)(g < 256u * 8u ? g : 256u * 8u);
-        switch (N) {
-#define PK_CASE(X) case X: launch_reg<X>(dev_tables, n_slice, vp, fast, dev_pair, grid, s); break;
-            PK_CASE(1) PK_CASE(2) PK_CASE(3) PK_CASE(4) PK_CASE(5) PK_CASE(6) PK_CASE(7) PK_CASE(8)
-#undef PK_CASE
-        }
-    } else {
+    {
         // 8x8 pair blocks, at most MAX_PB per launch; every launch streams all N tables once
         // (N <= 48: one launch; beyond that the extra launches re-read the tables).
         const int NB = (N + BLK - 1) / BLK;
@@ -263,7 +211,10 @@ int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int m
             // accumulators per lane: 64 / 128 / 192.  Measured at k=15 (TB/s, 1 slot vs 2): 3 blocks N=13 5.9 vs 5.8,
             // N=16 5.6 vs 5.9 (the register kernel: 5.1 / 4.7); 6 blocks N=24 4.9 vs 5.1; 10 blocks N=32 5.9 vs 4.2
             const int slots = pbs.n <= 3 ? (N <= 14 ? 1 : 2) : pbs.n <= 6 ? 2 : pbs.n <= 12 ? 1 : pbs.n <= 16 ? 2 : 3;
-            const int waves = (pbs.n + slots - 1) / slots;
+            int waves = (pbs.n + slots - 1) / slots;
+            // waves beyond the pair blocks only take part in the load phase; four of them pay off where the
+            // blocks alone give one wave (N <= 8: 5.4 vs 4.4 TB/s) or three (N 17-24: 5.9 vs 5.2 TB/s)
+            if ((pbs.n == 1 || pbs.n == 6) && waves < 4) waves = 4;
             if (lds > 64u * 1024u) {                       // opt in to more than 64 KiB of dynamic LDS
                 hipFuncSetAttribute((const void *)k_gram_blk<1, true, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 hipFuncSetAttribute((const void *)k_gram_blk<1, false, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
