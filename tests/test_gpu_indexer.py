@@ -176,6 +176,30 @@ def test_control_bytes_inside_sequence_lines(gpu):
         _check_against_oracle(gpu, data, k)
 
 
+def test_indexer_reuse_after_reset(gpu):
+    """One indexer, several genomes in a row (bench.py and a multi-sample run do this): nothing of an earlier
+    genome -- table bytes, histogram, record tallies, partition cursors -- may leak into the next one, whether
+    the next input is larger, much smaller, or empty."""
+    import synth
+    big, _ = synth.c2(6_000_000, seed=21)
+    small, _ = synth.c1(200_000, seed=22)
+    tiny = np.frombuffer(b">t\nACGTACGTTTGACCA\n", dtype=np.uint8)
+    for k in (9, 15):
+        with gpu.Indexer(k) as ix:
+            for data in (big, small, tiny, np.zeros(0, dtype=np.uint8), big, tiny):
+                ix.reset()
+                if data.size:
+                    ix.feed(data)
+                fin = ix.finish()
+                want = oracle.count_fasta(data, k)
+                assert fin["num_kmers"] == want["num_kmers"] and fin["total_bp"] == want["total_bp"], (k, data.size)
+                assert np.array_equal(ix.table_to_host(), want["table"]), (k, data.size)
+                assert np.array_equal(fin["hist256"][1:], oracle.table_stats(want["table"])[0]), (k, data.size)
+                assert int(fin["hist256"].sum()) == 4 ** k
+                recs = ix.records(fin["n_records"])
+                assert np.array_equal(recs["n_valid_kmers"], want["records"]["n_valid_kmers"])
+
+
 def test_random_structure_fuzz(gpu):
     """Random byte soup over the FASTA-relevant alphabet: every parser state transition, every seam."""
     rng = np.random.default_rng(11)
