@@ -750,9 +750,34 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8))) void 
         }
         if (pn) bump(pa, pn);
     };
+    // The same for a sparse bucket (histogram from the record side): the eight adds are issued back to back without
+    // looking at each other -- records outside the bucket or the part add zero to their counter -- and their
+    // returned values are evaluated afterwards: one LDS round trip instead of eight dependent ones.  Equal
+    // neighbours are not merged here; their adds return consecutive values, which moves the histogram the same way.
+    auto count8_sparse = [&](const uint4 &v, uint32_t i) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t old[8];
+        bool in[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t idx = i + q;
+            const uint32_t full = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
+            in[q] = idx >= start && idx < end && (full >> part_bits) == part;
+            const uint32_t a = full & (n_addr - 1u), sh = 16u * (a & 1u);
+            old[q] = (atomicAdd(&cnt[a >> 1], in[q] ? (1u << sh) : 0u) >> sh) & 0xffffu;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t c = old[q];
+            if (!in[q] || c >= 255u) continue;                           // nothing added, or already saturated
+            if (c == 0u) tally.d1++;
+            else if (c == 1u) { tally.d2++; tally.d1--; }
+            else { atomicAdd(&dh[c + 1u], 1); atomicAdd(&dh[c], -1); }
+        }
+    };
     constexpr int NIT = (K6_PIECE + T * 8 - 1) / (T * 8);               // 16-byte loads per lane and piece
     if (end - base <= (uint32_t)T * 8u) {                                // sparse bucket: the hoisted load was all of it
-        if (i_first < end) count8(v_first, i_first);
+        if (i_first < end) { if (by_rec) count8_sparse(v_first, i_first); else count8(v_first, i_first); }
         __syncthreads();
     } else {
         for (uint32_t p0 = base; p0 < end; p0 += K6_PIECE) {
