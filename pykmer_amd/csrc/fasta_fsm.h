@@ -137,6 +137,16 @@ __device__ __forceinline__ L2 shfl_up_l2(const L2 &v, int d) {
     return o;
 }
 __device__ __forceinline__ L2 wave_incl_scan_l2(L2 v, int lane, uint32_t km1) {
+    // Plain sequence text: every lane's piece restarts the window by itself (F_BRK: a break inside it, or >= k-1
+    // valid bases at its end), opens no record and leaves no pending blanks.  Then a prefix ending in lane i is
+    // lane i's own summary, except that F_FRONT is inherited from the leftmost piece (l2_compose keeps a's):
+    // no shuffles, no composition.
+    const uint32_t want = F_NONID | F_PRESET | F_BRK;
+    if (__all((v.flags & want) == want && v.rec == 0u && v.p_tail == 0ull)) {
+        const uint32_t front0 = (uint32_t)__builtin_amdgcn_readlane((int)v.flags, 0) & F_FRONT;
+        v.flags = (v.flags & ~F_FRONT) | front0;
+        return v;
+    }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         L2 o = shfl_up_l2(v, d);
