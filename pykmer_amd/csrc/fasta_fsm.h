@@ -121,6 +121,16 @@ __device__ __forceinline__ bool lane_state_dirty(const LaneState &o) { return (o
 
 // ---- wave / workgroup exclusive scans (64-wide wavefronts, non-commutative operator) ----------
 __device__ __forceinline__ L1 wave_incl_scan_l1(L1 v, int lane) {
+    // Short cut for the usual wave: no piece ends inside a header line, and a piece without a terminator ends in
+    // sequence text (it is not all blanks).  l1_compose then never lets an earlier piece's state through -- a
+    // terminator in b decides, and without one both START and SEQ before b give SEQ after it -- so the prefix
+    // ending in lane i has lane i's own end state, and "has a terminator" is an OR over the lanes up to i.
+    const uint32_t kind = l1_kind(v);
+    if (__all(v != 0u && kind != LS_HEADER && ((v & 1u) || kind == LS_SEQ))) {
+        const unsigned long long terms = __ballot((v & 1u) != 0u);
+        const unsigned long long upto = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+        return (v & ~1u) | ((terms & upto) ? 1u : 0u);
+    }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         L1 o = __shfl_up(v, d, 64);
