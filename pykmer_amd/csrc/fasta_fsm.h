@@ -187,10 +187,22 @@ __device__ __forceinline__ L2 wg_excl_scan_l2(const L2 &mine, const L2 &seed, L2
     L2 inc = wave_incl_scan_l2(mine, lane, km1);
     if (lane == 63) sh[w] = inc;
     __syncthreads();
-    L2 pre = seed;
-    for (int i = 0; i < w; i++) pre = l2_compose(pre, sh[i], km1);
-    L2 tot = pre;
-    for (int i = w; i < WG / 64; i++) tot = l2_compose(tot, sh[i], km1);
+    L2 pre = seed, tot;
+    // the same short cut one level up (see wave_incl_scan_l2): wave totals that each restart the window
+    // compose to "the last one, with the first one's F_FRONT"
+    const uint32_t want = F_NONID | F_PRESET | F_BRK;
+    bool plain = !(seed.flags & F_NONID);
+    for (int i = 0; i < WG / 64; i++) plain = plain && (sh[i].flags & want) == want && sh[i].rec == 0u && sh[i].p_tail == 0ull;
+    if (plain) {                                                         // uniform: sh[] is the same for every lane
+        const uint32_t front0 = sh[0].flags & F_FRONT;
+        if (w > 0) { pre = sh[w - 1]; pre.flags = (pre.flags & ~F_FRONT) | front0; }
+        tot = sh[WG / 64 - 1];
+        tot.flags = (tot.flags & ~F_FRONT) | front0;
+    } else {
+        for (int i = 0; i < w; i++) pre = l2_compose(pre, sh[i], km1);
+        tot = pre;
+        for (int i = w; i < WG / 64; i++) tot = l2_compose(tot, sh[i], km1);
+    }
     *total = tot;
     L2 up = shfl_up_l2(inc, 1);
     L2 res = (lane == 0) ? pre : l2_compose(pre, up, km1);
