@@ -70,6 +70,7 @@ __device__ __forceinline__ void hot_insert(HotTable &H, uint64_t addr, uint32_t 
                                            unsigned long long *side_n, uint64_t side_cap) {
     const unsigned long long key = addr + 1ull;
     uint32_t h = (uint32_t)((addr * 0x9E3779B97F4A7C15ull) >> 40) & (HOT_SLOTS - 1u);
+#pragma unroll 1                                               // rare path, inlined sixteen times into the walk loop: keep it small
     for (uint32_t t = 0; t < HOT_PROBES; t++) {
         unsigned long long old = atomicCAS(&H.key[h], 0ull, key);
         if (old == 0ull || old == key) {
