@@ -667,13 +667,10 @@ struct SliceTally {
 // `split_bits` > 0 (sparse tables, k=17): a bucket is shared by 2^split_bits workgroups, each reading all of the
 // bucket's (few) records but counting only its own part of the address range -- the LDS counters shrink
 // with the part, so several workgroups fit on a CU and hide each other's phases.
-// At most 64 vector registers: two of these 1024-thread workgroups must fit on a CU.
 template <int T>
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bucket_count(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
-                                                    uint32_t fb_bits, uint32_t split_bits, uint8_t *__restrict__ table8, uint32_t fresh,
-                                                    int *__restrict__ bucket_hist) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    __shared__ int dh[256];
+__device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
+                                                  uint32_t fb_bits, uint32_t split_bits, uint8_t *__restrict__ table8, uint32_t fresh,
+                                                  int *__restrict__ bucket_hist, uint8_t *smem, int *dh) {
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);                  // 2^fb_bits / 2 dwords
     const uint32_t fb = blockIdx.x >> split_bits, part = blockIdx.x & ((1u << split_bits) - 1u);
     const uint32_t start = final_start[fb], end = final_start[fb + 1];
@@ -839,6 +836,26 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8))) void 
     for (uint32_t i = threadIdx.x; i < 256; i += T) bucket_hist[(uint64_t)blockIdx.x * 256 + i] = dh[i];
 }
 
+// Two entry points for the same body.  A whole bucket (dense tables) needs all 128 KiB of LDS a workgroup may
+// have, so one workgroup sits on a CU whatever its register count -- no cap.  Half buckets (sparse tables) are
+// meant to run two to a CU, which takes at most 64 vector registers.
+template <int T>
+__global__ __launch_bounds__(T) void k_bucket_count(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
+                                                    uint32_t fb_bits, uint32_t split_bits, uint8_t *__restrict__ table8, uint32_t fresh,
+                                                    int *__restrict__ bucket_hist) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int dh[256];
+    bucket_count_body<T>(recs, final_start, fb_bits, split_bits, table8, fresh, bucket_hist, smem, dh);
+}
+template <int T>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_bucket_count_half(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start, uint32_t fb_bits, uint32_t split_bits,
+                         uint8_t *__restrict__ table8, uint32_t fresh, int *__restrict__ bucket_hist) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int dh[256];
+    bucket_count_body<T>(recs, final_start, fb_bits, split_bits, table8, fresh, bucket_hist, smem, dh);
+}
+
 // sums the per-bucket histogram rows into the running 256-bin histogram (signed deltas: two's complement adds)
 __global__ __launch_bounds__(256) void k_hist_reduce(const int *__restrict__ bucket_hist, uint32_t n_rows, unsigned long long *__restrict__ hist) {
     long long acc = 0;
@@ -985,6 +1002,7 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     hipFuncSetAttribute((const void *)k_scatter2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_scatter2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_bucket_count<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute((const void *)k_bucket_count_half<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (hipMemsetAsync(side_n, 0, 16, s) != hipSuccess) return -2;   // side-list length + the column scan's ticket counter
     if (pl.dbg && pl.k <= 15) {                              // diagnostic build of the walk (PK_DEBUG_WALK), timing only
         hipLaunchKernelGGL((k_walk_flat<uint32_t, uint32_t, true>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, pl,
@@ -1036,7 +1054,10 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
     const size_t lds6 = part_addrs * 2 < 64 ? 64 : part_addrs * 2;
     int *bucket_hist = (int *)(ws + lay.bucket_hist);
     const uint32_t n_rows6 = (uint32_t)(nfb << split);
-    hipLaunchKernelGGL(k_bucket_count<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, final_start, pl.fb_bits, split, table8, fresh ? 1u : 0u, bucket_hist);
+    if (split)
+        hipLaunchKernelGGL(k_bucket_count_half<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, final_start, pl.fb_bits, split, table8, fresh ? 1u : 0u, bucket_hist);
+    else
+        hipLaunchKernelGGL(k_bucket_count<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, final_start, pl.fb_bits, split, table8, fresh ? 1u : 0u, bucket_hist);
     hipLaunchKernelGGL(k_hist_reduce, dim3(n_rows6 < 16u ? 1u : (n_rows6 / 16u > 2048u ? 2048u : n_rows6 / 16u)), dim3(256), 0, s, (const int *)bucket_hist, n_rows6, hist);
     hipLaunchKernelGGL(k_apply_side, dim3(AS_WGS), dim3(WG), 0, s, side, side_n, lay.side_cap, table8, hist);
     return hipGetLastError() == hipSuccess ? 0 : -2;
