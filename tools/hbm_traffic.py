@@ -49,7 +49,7 @@ def main() -> None:
         "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, `bench.py --steps 2 --warmup 0 --no-cpu`), "
                  "largest dispatch per kernel (= the 800 Mbp k=15 step); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                  "MI355X_MICROARCH.md HBM section (FETCH_SIZE reads half of a wide coalesced stream on gfx950). "
-                 "Calibration: k_gram_reg<13> vs 13.96 GB algorithmic; k_chunk_l1 vs the 0.813 GB FASTA. "
+                 "Calibration: k_gram_blk (N=32) vs 34.36 GB algorithmic; k_chunk_l2 vs 0.813 GB FASTA + 0.203 GB lane states. "
                  "Derived by tools/hbm_traffic.py.",
         "_source": [fetch_csv, write_csv],
     }
