@@ -11,7 +11,7 @@
 // The kernel is HBM-bound (N * 4^k bytes); MFMA is deliberately not used.
 //
 //   k_gram_blk      N <= 128: masks of a 256-word tile staged in LDS, 8x8 table "pair blocks"
-//                   spread over the waves of the workgroup, accumulators (1-3 x 64) in registers.
+//                   spread over the waves of the workgroup, accumulators (1-2 x 64, or 2 x 32 packed) in registers.
 //                   (An all-in-registers kernel for N <= 16 was measured slower: N=13 5.1 vs 6.2 TB/s.)
 #include "pk_kernels.h"
 
@@ -89,7 +89,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // ------------------------------------------------------------------ any N: LDS-tiled ------------
 constexpr int BLK = 8;            // tables per block
 constexpr int TILE_WORDS = 256;   // 32-address words per tile (8 KiB of each table)
-constexpr int MAX_PB = 24;        // pair blocks per launch: 8 waves x 3 slots
+constexpr int MAX_PB = 24;        // pair blocks per launch: 12 waves x 2 slots
 
 struct PairBlocks {               // which 8x8 table-block pairs this launch tallies
     int n;
@@ -98,7 +98,9 @@ struct PairBlocks {               // which 8x8 table-block pairs this launch tal
 
 // SLOTS pair blocks per wave: 1 (7-12 pair blocks, N 25-32: one wave each, 64 accumulators per lane, more
 // waves sharing the load phase), 2 or 3 otherwise (see launch_gram).
-template <int SLOTS, bool FAST, int MAXT>
+// PACK: two 16-bit tallies per accumulator register (a lane adds at most 128 per tile to a tally, and the
+// launcher keeps a workgroup below 448 tiles), halving the accumulator registers where three slots would spill.
+template <int SLOTS, bool FAST, int MAXT, bool PACK>
 __global__ __launch_bounds__(MAXT) void k_gram_blk(const uint8_t *const *__restrict__ tables, int N, uint64_t n, ValidParams vp,
                                                   PairBlocks pbs, unsigned long long *__restrict__ pair) {
     extern __shared__ uint32_t masks[];                 // [NB*BLK][TILE_WORDS]
@@ -111,13 +113,14 @@ __global__ __launch_bounds__(MAXT) void k_gram_blk(const uint8_t *const *__restr
         bi[s] = pb < pbs.n ? pbs.bi[pb] : -1;
         bj[s] = pb < pbs.n ? pbs.bj[pb] : -1;
     }
-    uint32_t acc[SLOTS][BLK][BLK];
+    constexpr int AJ = PACK ? BLK / 2 : BLK;
+    uint32_t acc[SLOTS][BLK][AJ];
 #pragma unroll
     for (int s = 0; s < SLOTS; s++)
 #pragma unroll
         for (int i = 0; i < BLK; i++)
 #pragma unroll
-            for (int j = 0; j < BLK; j++) acc[s][i][j] = 0;
+            for (int j = 0; j < AJ; j++) acc[s][i][j] = 0;
 
     const uint64_t n_words = n_words_for(n);
     const uint64_t n_tiles = (n_words + TILE_WORDS - 1) / TILE_WORDS;
@@ -164,7 +167,10 @@ __global__ __launch_bounds__(MAXT) void k_gram_blk(const uint8_t *const *__restr
 #pragma unroll
                 for (int i = 0; i < BLK; i++)
 #pragma unroll
-                    for (int j = 0; j < BLK; j++) acc[s][i][j] += __builtin_popcount(a[i] & b[j]);
+                    for (int j = 0; j < AJ; j++) {
+                        if (PACK) acc[s][i][j] += (uint32_t)__builtin_popcount(a[i] & b[2 * j]) + ((uint32_t)__builtin_popcount(a[i] & b[2 * j + 1]) << 16);
+                        else acc[s][i][j] += __builtin_popcount(a[i] & b[j]);
+                    }
             }
         }
         __syncthreads();
@@ -177,7 +183,8 @@ __global__ __launch_bounds__(MAXT) void k_gram_blk(const uint8_t *const *__restr
 #pragma unroll
             for (int j = 0; j < BLK; j++) {
                 int gi = bi[s] * BLK + i, gj = bj[s] * BLK + j;
-                uint32_t v = wave_sum(acc[s][i][j]);
+                const uint32_t mine = PACK ? (acc[s][i][j >> 1] >> (16 * (j & 1))) & 0xffffu : acc[s][i][PACK ? 0 : j];
+                uint32_t v = wave_sum(mine);
                 if (lane == 0 && v && gi < N && gj < N && gi <= gj) atomicAdd(&pair[gi * N + gj], (unsigned long long)v);
             }
     }
@@ -204,34 +211,40 @@ int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int m
         const size_t lds = (size_t)NB * BLK * TILE_WORDS * sizeof(uint32_t);
         uint64_t n_tiles = (n_words + TILE_WORDS - 1) / TILE_WORDS;
         uint32_t grid = (uint32_t)(n_tiles < 1024u ? n_tiles : 1024u);
+        if ((n_tiles + grid - 1) / grid > 448u) grid = (uint32_t)((n_tiles + 447u) / 448u);   // packed 16-bit tallies: <= 448 tiles per workgroup
         PairBlocks pbs;
         pbs.n = 0;
         auto flush = [&]() {
             if (!pbs.n) return;
-            // accumulators per lane: 64 / 128 / 192.  Measured at k=15 (TB/s, 1 slot vs 2): 3 blocks N=13 5.9 vs 5.8,
-            // N=16 5.6 vs 5.9 (the register kernel: 5.1 / 4.7); 6 blocks N=24 4.9 vs 5.1; 10 blocks N=32 5.9 vs 4.2
-            const int slots = pbs.n <= 3 ? (N <= 14 ? 1 : 2) : pbs.n <= 6 ? 2 : pbs.n <= 12 ? 1 : pbs.n <= 16 ? 2 : 3;
+            // Shape per number of pair blocks, measured at k=15 (TB/s):
+            //    1 block   (N <= 8)    1 slot, 4 waves (3 of them only load)          5.5
+            //    3 blocks  (N 9-16)    N <= 14: 1 slot, 3 waves 6.1; else 2 slots, 2 waves 6.0
+            //    6 blocks  (N 17-24)   2 slots, 4 waves (one only loads)              5.8
+            //   10 blocks  (N 25-32)   1 slot, 10 waves                               6.1   (2 slots: 4.2)
+            //   15 blocks  (N 33-40)   2 slots, 8 waves                               5.5   (packed: 5.2)
+            //   21 blocks  (N 41-48)   2 slots of packed 16-bit tallies, 11 waves     5.3   (3 slots of 32-bit tallies spill: 4.1)
+            //   more: 24 blocks per launch, every launch streams all N tables again
+            const int slots = pbs.n <= 3 ? (N <= 14 ? 1 : 2) : pbs.n <= 6 ? 2 : pbs.n <= 12 ? 1 : 2;
+            const bool pack = pbs.n > 16;
             int waves = (pbs.n + slots - 1) / slots;
-            // waves beyond the pair blocks only take part in the load phase; four of them pay off where the
-            // blocks alone give one wave (N <= 8: 5.4 vs 4.4 TB/s) or three (N 17-24: 5.9 vs 5.2 TB/s)
-            if ((pbs.n == 1 || pbs.n == 6) && waves < 4) waves = 4;
+            if ((pbs.n == 1 || pbs.n == 6) && waves < 4) waves = 4;   // waves beyond the pair blocks take part in the load phase only
             if (lds > 64u * 1024u) {                       // opt in to more than 64 KiB of dynamic LDS
-                hipFuncSetAttribute((const void *)k_gram_blk<1, true, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void *)k_gram_blk<1, false, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void *)k_gram_blk<2, true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void *)k_gram_blk<2, false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void *)k_gram_blk<3, true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void *)k_gram_blk<3, false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<1, true, 768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<1, false, 768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<2, true, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<2, false, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<2, true, 768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipFuncSetAttribute((const void *)k_gram_blk<2, false, 768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             }
             if (slots == 1) {
-                if (fast) hipLaunchKernelGGL((k_gram_blk<1, true, 768>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
-                else hipLaunchKernelGGL((k_gram_blk<1, false, 768>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
-            } else if (slots == 2) {
-                if (fast) hipLaunchKernelGGL((k_gram_blk<2, true, 512>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
-                else hipLaunchKernelGGL((k_gram_blk<2, false, 512>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+                if (fast) hipLaunchKernelGGL((k_gram_blk<1, true, 768, false>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+                else hipLaunchKernelGGL((k_gram_blk<1, false, 768, false>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+            } else if (!pack) {
+                if (fast) hipLaunchKernelGGL((k_gram_blk<2, true, 512, false>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+                else hipLaunchKernelGGL((k_gram_blk<2, false, 512, false>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
             } else {
-                if (fast) hipLaunchKernelGGL((k_gram_blk<3, true, 512>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
-                else hipLaunchKernelGGL((k_gram_blk<3, false, 512>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+                if (fast) hipLaunchKernelGGL((k_gram_blk<2, true, 768, true>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
+                else hipLaunchKernelGGL((k_gram_blk<2, false, 768, true>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);
             }
             pbs.n = 0;
         };

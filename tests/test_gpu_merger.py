@@ -20,7 +20,7 @@ def _random_tables(rng, N, n, density=0.4):
     return out
 
 
-@pytest.mark.parametrize("N", [2, 3, 5, 8, 13, 16, 17, 24, 32, 40, 49, 64])
+@pytest.mark.parametrize("N", [2, 3, 5, 8, 9, 13, 16, 17, 24, 25, 32, 33, 40, 41, 48, 49, 64])
 def test_gram_vs_oracle(gpu, N):
     rng = np.random.default_rng(100 + N)
     n = 4 ** 7
