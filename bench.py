@@ -22,6 +22,54 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def spawn_ranks(world: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) and relay
+    rank 0's JSON line.  The parent never touches the GPU (no torch import, no HIP call), so nothing here is
+    an exec of a GPU-initialised process; the ranks are plain child processes."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):       # a rank died: its peers would wait in a collective for ever
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                                     # exactly the children started above
+            break
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"model": model, "nproc": os.cpu_count(), "usable_by_this_process": len(os.sched_getaffinity(0))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -35,9 +83,12 @@ def main():
     ap.add_argument("--no-merge32", action="store_true", help="skip the 32-table merge (config 5 shape)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-bp", type=int, default=160_000_000, help="sample size for the CPU baseline")
-    ap.add_argument("--cpu-threads", type=int, default=16,
-                    help="threads of the all-cores CPU leg (capped by the process's CPU affinity; 16 = one GPU's host share)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the all-cores CPU legs (default 0 = every core this process may run on)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import synth
@@ -124,7 +175,7 @@ def main():
         traffic = tj.get(dominant, {}).get("bytes_per_launch")
         pipeline_traffic = tj.get("_pipeline_bytes_per_step")
     out = {
-        "metric": "bp/s k-mer counted (k=15, 1 GPU)" if k == 15 else f"bp/s k-mer counted (k={k})",
+        "metric": f"bp/s k-mer counted (k={k}, {world} GPU{'s' if world > 1 else ''})",
         "value": value, "unit": "bp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -176,10 +227,35 @@ def main():
             best = float(tt.item())
         total = d_pair.view(N, N).cpu().numpy()
         assert all(total[i, j] <= min(total[i, i], total[j, j]) for i in range(N) for j in range(i + 1, N))
-        return {"n_tables": N, "k": k, "seconds": best, "kernel_seconds_rank0": kern, "algorithmic_bytes": N * n,
-                "kernel_GBps_aggregate": N * n / kern / 1e9 if world == 1 else None,
-                "end_to_end_GBps_aggregate": N * n / best / 1e9,
-                "sharding": f"address range / {world} + all_reduce(N*N u64)" if world > 1 else "single GPU"}
+        res = {"n_tables": N, "k": k, "seconds": best, "kernel_seconds_rank0": kern, "algorithmic_bytes": N * n,
+               "kernel_GBps_aggregate": N * n / kern / 1e9 if world == 1 else None,
+               "end_to_end_GBps_aggregate": N * n / best / 1e9,
+               "sharding": f"address range / {world} + all_reduce(N*N u64)" if world > 1 else "single GPU"}
+        if rank == 0 and world == 1 and not args.no_cpu:
+            # CPU baseline of the merge: the reference's pair loop (tools.py:439-493 per pair, merger.py:137-153 over a
+            # pool) restated in C, on a bounded slice of the address range of the SAME tables; the pair loop's cost is
+            # linear in the slice, so the full-size figure is the slice time scaled by n / slice
+            import oracle
+            pairs = N * (N - 1) // 2
+            m = max(2048, min(n, int(2.5e9 / (2 * pairs))) & ~2047)
+            host = [sl[:m].cpu().numpy() for sl in slices]
+            t0 = time.perf_counter()
+            ref = oracle.gram_mt(host, 1, 255, 1)
+            dt1 = time.perf_counter() - t0
+            avail = len(os.sched_getaffinity(0))
+            threads = max(1, min(args.cpu_threads, avail) if args.cpu_threads > 0 else avail)
+            t0 = time.perf_counter()
+            ref_mt = oracle.gram_mt(host, 1, 255, threads)
+            dtn = time.perf_counter() - t0
+            gpu_slice, _ = _lib.gram_device_partial(ptrs, m, 1, 255, device=local)
+            same = bool(np.array_equal(_lib.gram_expand(gpu_slice), ref) and np.array_equal(ref, ref_mt))
+            res["cpu_baseline"] = {
+                "value": dt1 * n / m, "unit": "s", "cores": 1, "kind": "port",
+                "sample": f"oracle pko_gram_mt, {pairs} pairs over addresses [0, {m}) of the same {N} tables ({dt1:.1f} s), scaled by {n // m}",
+                "all_cores": {"value": dtn * n / m, "unit": "s", "cores": threads, "kind": "port",
+                              "sample": f"same slice, pairs spread over {threads} threads ({dtn:.2f} s)"},
+                "slice_equals_gpu": same, "host": cpu_info()}
+        return res
 
     if not args.no_merge:                                               # secondary objects: never allowed to cost the bench line
         def guarded(n_tables):
@@ -209,7 +285,9 @@ def main():
                                    "host_cores_available": os.cpu_count()}
             # the same port on the host cores this process may use, on the WHOLE workload; its table is also
             # compared with the one the GPU built -- a second, independent full-size parity check
-            threads = max(1, min(args.cpu_threads, len(os.sched_getaffinity(0))))
+            avail = len(os.sched_getaffinity(0))
+            threads = max(1, min(args.cpu_threads, avail) if args.cpu_threads > 0 else avail)
+            out["cpu_baseline"]["host"] = cpu_info()
             step()                                                          # the merge section reused the indexer: recount
             gpu_table = ix.table_to_host()
             t0 = time.perf_counter()

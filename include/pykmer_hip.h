@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 1
+#define PK_ABI_VERSION 2
 
 enum {
     PK_OK = 0,
@@ -48,6 +48,8 @@ int pk_dev_alloc(void **dev_out, uint64_t n_bytes, int device);
 int pk_dev_free(void *dev, int device);
 int pk_dev_upload(void *dev_dst, const void *host_src, uint64_t n_bytes, int device);
 int pk_dev_download(void *host_dst, const void *dev_src, uint64_t n_bytes, int device);
+/* Free / total HBM on `device` in bytes: lets the host size how many table slices it stages beside each other. */
+int pk_dev_mem_info(uint64_t *free_out, uint64_t *total_out, int device);
 
 /* ---- indexer: replaces gen_kmers + canonical min + process_kmers (indexer.py:130-160, 341, 162-297)
  * and the parser that feeds them (indexer.py:45-99).  k must be odd, 1 <= k <= 17 (tools.py:165-167).
@@ -118,6 +120,11 @@ int pk_gram(const uint8_t *const *tables, int N, uint64_t n, int min_count, int 
 int pk_gram_device_partial(const void *const *dev_tables, int N, uint64_t n_slice, int min_count,
                            int max_count, uint64_t *pair_out, void *dev_pair_out, int device,
                            double *kernel_seconds_out);
+/* Same scan, but the tallies are ADDED to dev_pair_accum (device, N*N u64, zeroed by the caller before the
+ * first slice): a rank whose share of the address range does not fit HBM beside N tables scans it in
+ * sub-slices, and the accumulator is what the RCCL all-reduce sums across ranks (merger.py:163-178). */
+int pk_gram_device_accumulate(const void *const *dev_tables, int N, uint64_t n_slice, int min_count,
+                              int max_count, void *dev_pair_accum, int device, double *kernel_seconds_out);
 int pk_gram_expand(const uint64_t *pair, int N, uint64_t *matrix_out);
 
 #ifdef __cplusplus

@@ -46,6 +46,9 @@ def _load():
         lib.pko_gram.restype = ctypes.c_int
         lib.pko_gram.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_void_p]
+        lib.pko_gram_mt.restype = ctypes.c_int
+        lib.pko_gram_mt.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_void_p, ctypes.c_int]
         _lib = lib
     return _lib
 
@@ -117,5 +120,17 @@ def gram(tables, min_count: int = 1, max_count: int = 255) -> np.ndarray:
     m = np.zeros((n, n, 3), dtype=np.uint64)
     rc = lib.pko_gram(ptrs, n, ts[0].size, min_count, max_count, m.ctypes.data)
     if rc != 0:
+        raise ValueError("oracle rejected min/max count")
+    return m
+
+
+def gram_mt(tables, min_count: int = 1, max_count: int = 255, threads: int = 1) -> np.ndarray:
+    """The pair loop spread over `threads` host threads (merger.py:137-153's pool); same matrix as gram()."""
+    lib = _load()
+    ts = [np.ascontiguousarray(t, dtype=np.uint8) for t in tables]
+    n = len(ts)
+    ptrs = (ctypes.c_void_p * n)(*[t.ctypes.data for t in ts])
+    m = np.zeros((n, n, 3), dtype=np.uint64)
+    if lib.pko_gram_mt(ptrs, n, ts[0].size, min_count, max_count, m.ctypes.data, int(threads)) != 0:
         raise ValueError("oracle rejected min/max count")
     return m

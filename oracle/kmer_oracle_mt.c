@@ -146,3 +146,34 @@ int pko_count_fasta_mt(const uint8_t *fasta, uint64_t n_bytes, int k, uint8_t *t
     free(split); free(hdrs); free(kmers); free(bps);
     return 0;
 }
+
+/*
+ * pko_gram_mt -- the merger's pair loop on `threads` host threads, the way merger.py:137-153 spreads
+ * pairs over a process pool: each (k, l) pair is one task that walks both tables
+ * (Header.calculate_distance, tools.py:439-493: s_valid, o_valid, their sums and the sum of the AND).
+ * Same output layout as pko_gram.  bench.py times it as the merge's CPU baseline (threads = 1 and all cores).
+ */
+int pko_gram_mt(const uint8_t *const *tables, int N, uint64_t n, int min_count, int max_count,
+                uint64_t *matrix, int threads) {
+    if (min_count < 1 || max_count > 255) return -1;                 /* merger.py:90-91 */
+    const int n_pairs = N * (N - 1) / 2;
+    int *pi = (int *)malloc(sizeof(int) * (size_t)(n_pairs > 0 ? n_pairs : 1)), *pj = (int *)malloc(sizeof(int) * (size_t)(n_pairs > 0 ? n_pairs : 1));
+    int p = 0;
+    for (int i = 0; i < N; i++)
+        for (int j = i + 1; j < N; j++) { pi[p] = i; pj[p] = j; p++; }
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+    for (int q = 0; q < n_pairs; q++) {
+        const uint8_t *a = tables[pi[q]], *b = tables[pj[q]];
+        uint64_t ta = 0, tb = 0, sh = 0;
+        for (uint64_t x = 0; x < n; x++) {                           /* tools.py:473-482 */
+            const int va = a[x] >= min_count && a[x] <= max_count, vb = b[x] >= min_count && b[x] <= max_count;
+            ta += (uint64_t)va; tb += (uint64_t)vb; sh += (uint64_t)(va & vb);
+        }
+        uint64_t *ij = matrix + ((uint64_t)pi[q] * N + pj[q]) * 3, *ji = matrix + ((uint64_t)pj[q] * N + pi[q]) * 3;
+        ij[0] = ta; ij[1] = tb; ij[2] = sh;                          /* merger.py:175-176 */
+        ji[0] = tb; ji[1] = ta; ji[2] = sh;
+    }
+    free(pi); free(pj);
+    return 0;
+}

@@ -23,6 +23,7 @@ _SIGNATURES = {
     "pk_dev_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pk_dev_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]),
     "pk_dev_download": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]),
+    "pk_dev_mem_info": (ctypes.c_int, [_u64p, _u64p, ctypes.c_int]),
     "pk_count_fasta": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, _u64p, _u64p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, _u64p, ctypes.c_int]),
     "pk_indexer_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
@@ -42,6 +43,8 @@ _SIGNATURES = {
     "pk_gram_device_partial": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                ctypes.POINTER(ctypes.c_double)]),
+    "pk_gram_device_accumulate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "pk_gram_expand": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)
@@ -113,6 +116,13 @@ def device_count() -> int:
     return load().pk_device_count()
 
 
+def mem_info(device: int = 0):
+    """(free, total) bytes of HBM on `device`."""
+    f, t = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    _check(load().pk_dev_mem_info(ctypes.byref(f), ctypes.byref(t), device))
+    return int(f.value), int(t.value)
+
+
 def _hist_out():
     return np.zeros(256, dtype=np.uint64)
 
@@ -125,6 +135,9 @@ class DeviceBuffer:
         p = ctypes.c_void_p()
         _check(load().pk_dev_alloc(ctypes.byref(p), self.n, device))
         self.ptr = p.value
+
+    def zero(self):
+        self.upload(np.zeros(self.n, dtype=np.uint8))
 
     def upload(self, data, offset: int = 0):
         buf = _as_u8(data)
@@ -264,6 +277,17 @@ def gram_device_partial(dev_ptrs, n_slice: int, min_count: int = 1, max_count: i
                                          ctypes.c_void_p(dev_pair_out) if dev_pair_out else None, device,
                                          ctypes.byref(secs)))
     return pair, secs.value
+
+
+def gram_device_accumulate(dev_ptrs, n_slice: int, dev_pair_accum: int, min_count: int = 1, max_count: int = 255,
+                           device: int = 0) -> float:
+    """pk_gram_device_accumulate: adds one slice's tallies to an N x N u64 accumulator in HBM; returns kernel seconds."""
+    N = len(dev_ptrs)
+    ptrs = (ctypes.c_void_p * N)(*dev_ptrs)
+    secs = ctypes.c_double(0)
+    _check(load().pk_gram_device_accumulate(ptrs, N, n_slice, min_count, max_count, ctypes.c_void_p(dev_pair_accum), device,
+                                            ctypes.byref(secs)))
+    return secs.value
 
 
 def gram_expand(pair: np.ndarray) -> np.ndarray:

@@ -125,6 +125,63 @@ def decompress_file(path: str, expected_size: int = None, threads: int = DEFAULT
     return data
 
 
+def decompress_range(path: str, lo: int, hi: int, threads: int = DEFAULT_THREADS) -> Tuple[np.ndarray, int]:
+    """Uncompressed bytes [lo, hi) of a gzip / BGZF file -> (array, bytes inflated to get them).
+
+    BGZF: the block list comes from the `.gzi` beside the file when there is one (gzireader.py:12-34 layout),
+    otherwise from walking the block headers (18 bytes each, no inflation); only the blocks overlapping the
+    range are inflated, in parallel.  Any other gzip stream is read sequentially up to `hi`."""
+    if hi <= lo:
+        return np.zeros(0, dtype=np.uint8), 0
+    if not is_bgzf(path):
+        with gzip.open(path, "rb") as fh:
+            left = lo
+            while left:                                      # no seeking in a plain deflate stream
+                got = fh.read(min(left, 1 << 24))
+                if not got:
+                    break
+                left -= len(got)
+            data = np.frombuffer(fh.read(hi - lo), dtype=np.uint8)
+        return data, hi
+    raw = np.memmap(path, dtype=np.uint8, mode="r")
+    buf = memoryview(raw)
+    gzi = path + ".gzi"
+    if os.path.exists(gzi):
+        entries = [(0, 0)] + read_gzi(gzi)                   # every block's (compressed, uncompressed) start
+        c_offs = [c for c, _ in entries]
+        u_offs = [u for _, u in entries]
+        first = max(0, int(np.searchsorted(u_offs, lo, side="right")) - 1)
+        blocks, offs = [], []
+        i = first
+        while i < len(entries) and u_offs[i] < hi:
+            c_end = c_offs[i + 1] if i + 1 < len(entries) else None
+            if c_end is None:                                # last indexed block: its size is in its own header
+                c_end = c_offs[i] + struct.unpack_from("<H", buf, c_offs[i] + 16)[0] + 1
+            blocks.append((c_offs[i], c_end - c_offs[i]))
+            offs.append(u_offs[i])
+            i += 1
+    else:
+        blocks, offs, u = [], [], 0
+        for off, size in scan_blocks(buf):
+            isize = struct.unpack_from("<I", buf, off + size - 4)[0]
+            if u + isize > lo and u < hi:
+                blocks.append((off, size))
+                offs.append(u)
+            u += isize
+            if u >= hi:
+                break
+    if not blocks:
+        raise OSError(f"{path}: range [{lo}, {hi}) is outside the file")
+    sizes = [struct.unpack_from("<I", buf, off + size - 4)[0] for off, size in blocks]
+    base = offs[0]
+    span = np.empty(offs[-1] + sizes[-1] - base, dtype=np.uint8)
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        list(pool.map(lambda i: _inflate_block(buf, blocks[i][0], blocks[i][1], span, offs[i] - base), range(len(blocks))))
+    if base + span.size < hi:
+        raise OSError(f"{path}: ends before byte {hi}")
+    return span[lo - base: hi - base], int(span.size)
+
+
 def is_bgzf(path: str) -> bool:
     with open(path, "rb") as fh:
         head = fh.read(18)

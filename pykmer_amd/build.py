@@ -12,14 +12,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpykmer_hip.so")
 SOURCES = ["kmer_count.hip", "kmer_part.hip", "gram_scan.hip", "pk_api.hip"]
-HEADERS = ["fasta_fsm.h", "pk_kernels.h", os.path.join("..", "..", "include", "pykmer_hip.h")]
+
+
+def _deps():
+    """Everything the library is compiled from: every .hip / .h under csrc/ plus the public header."""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))) + \
+        [os.path.join(HERE, "..", "include", "pykmer_hip.h"), os.path.abspath(__file__)]
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > t for f in _deps())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -192,9 +192,9 @@ __global__ __launch_bounds__(MAXT) void k_gram_blk(const uint8_t *const *__restr
 
 // ------------------------------------------------------------------ launcher --------------------
 int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int min_count, int max_count,
-                unsigned long long *dev_pair, hipStream_t s) {
+                unsigned long long *dev_pair, bool zero_first, hipStream_t s) {
     if (N < 1 || N > 128) return -1;                      // 128 tables x 256 words x 4 B = 128 KiB of LDS
-    if (hipMemsetAsync(dev_pair, 0, sizeof(unsigned long long) * (size_t)N * N, s) != hipSuccess) return -2;
+    if (zero_first && hipMemsetAsync(dev_pair, 0, sizeof(unsigned long long) * (size_t)N * N, s) != hipSuccess) return -2;
     if (n_slice == 0) return 0;
     ValidParams vp;
     vp.lo_rep = (uint32_t)(min_count & 0x7f) * 0x01010101u;
@@ -211,7 +211,11 @@ int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int m
         const size_t lds = (size_t)NB * BLK * TILE_WORDS * sizeof(uint32_t);
         uint64_t n_tiles = (n_words + TILE_WORDS - 1) / TILE_WORDS;
         uint32_t grid = (uint32_t)(n_tiles < 1024u ? n_tiles : 1024u);
-        if ((n_tiles + grid - 1) / grid > 448u) grid = (uint32_t)((n_tiles + 447u) / 448u);   // packed 16-bit tallies: <= 448 tiles per workgroup
+        // packed 16-bit tallies (PACK): per tile a lane adds TILE_WORDS / 64 popcounts of at most 32 to one tally
+        // (128 in all), so 448 tiles per workgroup stay below 2^16 and never carry into the neighbouring tally
+        constexpr uint32_t MAX_TILES_PER_WG = 448;
+        static_assert(MAX_TILES_PER_WG * (TILE_WORDS / 64) * 32 < 65536, "16-bit packed tallies would overflow");
+        if ((n_tiles + grid - 1) / grid > MAX_TILES_PER_WG) grid = (uint32_t)((n_tiles + MAX_TILES_PER_WG - 1) / MAX_TILES_PER_WG);
         PairBlocks pbs;
         pbs.n = 0;
         auto flush = [&]() {
@@ -228,13 +232,18 @@ int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int m
             const bool pack = pbs.n > 16;
             int waves = (pbs.n + slots - 1) / slots;
             if ((pbs.n == 1 || pbs.n == 6) && waves < 4) waves = 4;   // waves beyond the pair blocks take part in the load phase only
-            if (lds > 64u * 1024u) {                       // opt in to more than 64 KiB of dynamic LDS
-                hipFuncSetAttribute((const void *)k_gram_blk<1, true, 768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void *)k_gram_blk<1, false, 768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void *)k_gram_blk<2, true, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void *)k_gram_blk<2, false, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void *)k_gram_blk<2, true, 768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipFuncSetAttribute((const void *)k_gram_blk<2, false, 768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            int dev = 0;
+            hipGetDevice(&dev);
+            static size_t lds_opted[64] = {};                // per device: the dynamic-LDS limit already granted
+            if (lds > 64u * 1024u && lds > lds_opted[dev & 63]) {   // opt in to more than 64 KiB of dynamic LDS, once
+                lds_opted[dev & 63] = 128u * 1024u;
+                const int lds_max = 128 * 1024;
+                hipFuncSetAttribute((const void *)k_gram_blk<1, true, 768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+                hipFuncSetAttribute((const void *)k_gram_blk<1, false, 768, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+                hipFuncSetAttribute((const void *)k_gram_blk<2, true, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+                hipFuncSetAttribute((const void *)k_gram_blk<2, false, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+                hipFuncSetAttribute((const void *)k_gram_blk<2, true, 768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+                hipFuncSetAttribute((const void *)k_gram_blk<2, false, 768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
             }
             if (slots == 1) {
                 if (fast) hipLaunchKernelGGL((k_gram_blk<1, true, 768, false>), dim3(grid), dim3(64 * waves), lds, s, dev_tables, N, n_slice, vp, pbs, dev_pair);

@@ -80,6 +80,15 @@ extern "C" int pk_dev_download(void *host_dst, const void *dev_src, uint64_t n_b
     return PK_OK;
 }
 
+extern "C" int pk_dev_mem_info(uint64_t *free_out, uint64_t *total_out, int device) {
+    HIPCHK(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_out) *free_out = f;
+    if (total_out) *total_out = t;
+    return PK_OK;
+}
+
 // ================================================================== indexer ====================
 struct pk_indexer {
     int k = 0, device = 0;
@@ -449,40 +458,70 @@ extern "C" int pk_gram_expand(const uint64_t *pair, int N, uint64_t *matrix_out)
     return PK_OK;
 }
 
-extern "C" int pk_gram_device_partial(const void *const *dev_tables, int N, uint64_t n_slice, int min_count, int max_count,
-                                      uint64_t *pair_out, void *dev_pair_out, int device, double *kernel_seconds_out) {
+// Per-device scan context: the table-pointer array in HBM, a stream and two events, created once and reused by
+// every scan on that device (a 2 ms kernel should not pay for hipMalloc / hipEventCreate each call).
+#include <mutex>
+#include <thread>
+namespace {
+struct GramCtx {
+    std::mutex mu;
+    const uint8_t **d_ptrs = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    unsigned long long *d_pair = nullptr;      // scratch N x N for callers that only want the host copy
+};
+constexpr int MAX_DEVICES = 64;
+GramCtx g_gram[MAX_DEVICES];
+
+int gram_ctx(int device, GramCtx **out) {
+    if (device < 0 || device >= MAX_DEVICES) return fail(PK_ERR_ARG, "device ordinal %d out of range", device);
+    GramCtx &c = g_gram[device];
+    if (!c.d_ptrs) {
+        HIPCHK(hipMalloc(&c.d_ptrs, 128 * sizeof(void *)));
+        HIPCHK(hipMalloc(&c.d_pair, 128 * 128 * sizeof(unsigned long long)));
+        HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&c.e0));
+        HIPCHK(hipEventCreate(&c.e1));
+    }
+    *out = &c;
+    return PK_OK;
+}
+
+// one scan of N device-resident slices; `accumulate` adds into dev_pair instead of overwriting it
+int gram_scan_device(const void *const *dev_tables, int N, uint64_t n_slice, int min_count, int max_count, uint64_t *pair_out,
+                     void *dev_pair, bool accumulate, int device, double *kernel_seconds_out) {
     int rc = check_counts(N, min_count, max_count);
     if (rc) return rc;
     if (!dev_tables) return fail(PK_ERR_ARG, "null table list");
     for (int i = 0; i < N; i++)
         if (!dev_tables[i] || ((uintptr_t)dev_tables[i] & 15u)) return fail(PK_ERR_ARG, "table %d: device pointer must be 16-byte aligned", i);
     HIPCHK(hipSetDevice(device));
-    const uint8_t **d_ptrs = nullptr;
-    unsigned long long *d_pair = (unsigned long long *)dev_pair_out;
-    bool own_pair = false;
-    HIPCHK(hipMalloc(&d_ptrs, N * sizeof(void *)));
-    if (!d_pair) {
-        hipError_t e = hipMalloc(&d_pair, (size_t)N * N * sizeof(unsigned long long));
-        if (e != hipSuccess) { hipFree(d_ptrs); return fail(PK_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
-        own_pair = true;
-    }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    rc = PK_OK;
-    if (hipMemcpy(d_ptrs, dev_tables, N * sizeof(void *), hipMemcpyHostToDevice) != hipSuccess) rc = fail(PK_ERR_HIP, "pointer upload failed");
-    if (!rc) {
-        hipEventRecord(e0, 0);
-        int lr = launch_gram(d_ptrs, N, n_slice, min_count, max_count, d_pair, 0);
-        hipEventRecord(e1, 0);
-        if (lr || hipDeviceSynchronize() != hipSuccess) rc = fail(PK_ERR_HIP, "gram kernel failed: %s", hipGetErrorString(hipGetLastError()));
-    }
-    if (!rc && kernel_seconds_out) { float ms = 0; hipEventElapsedTime(&ms, e0, e1); *kernel_seconds_out = ms * 1e-3; }
-    if (!rc && pair_out && hipMemcpy(pair_out, d_pair, (size_t)N * N * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess)
-        rc = fail(PK_ERR_HIP, "result download failed");
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(d_ptrs);
-    if (own_pair) hipFree(d_pair);
-    return rc;
+    GramCtx *c = nullptr;
+    if ((rc = gram_ctx(device, &c))) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    unsigned long long *d_pair = dev_pair ? (unsigned long long *)dev_pair : c->d_pair;
+    if (!dev_pair) accumulate = false;
+    HIPCHK(hipMemcpyAsync(c->d_ptrs, dev_tables, N * sizeof(void *), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->e0, c->stream));
+    if (launch_gram(c->d_ptrs, N, n_slice, min_count, max_count, d_pair, !accumulate, c->stream))
+        return fail(PK_ERR_HIP, "gram kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    HIPCHK(hipEventRecord(c->e1, c->stream));
+    if (pair_out) HIPCHK(hipMemcpyAsync(pair_out, d_pair, (size_t)N * N * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (kernel_seconds_out) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->e0, c->e1)); *kernel_seconds_out = ms * 1e-3; }
+    return PK_OK;
+}
+}  // namespace
+
+extern "C" int pk_gram_device_partial(const void *const *dev_tables, int N, uint64_t n_slice, int min_count, int max_count,
+                                      uint64_t *pair_out, void *dev_pair_out, int device, double *kernel_seconds_out) {
+    return gram_scan_device(dev_tables, N, n_slice, min_count, max_count, pair_out, dev_pair_out, false, device, kernel_seconds_out);
+}
+
+extern "C" int pk_gram_device_accumulate(const void *const *dev_tables, int N, uint64_t n_slice, int min_count, int max_count,
+                                         void *dev_pair_accum, int device, double *kernel_seconds_out) {
+    if (!dev_pair_accum) return fail(PK_ERR_ARG, "null accumulator");
+    return gram_scan_device(dev_tables, N, n_slice, min_count, max_count, nullptr, dev_pair_accum, true, device, kernel_seconds_out);
 }
 
 extern "C" int pk_gram(const uint8_t *const *tables, int N, uint64_t n, int min_count, int max_count, uint64_t *matrix_out,
@@ -492,23 +531,52 @@ extern "C" int pk_gram(const uint8_t *const *tables, int N, uint64_t n, int min_
     if (!tables || !matrix_out) return fail(PK_ERR_ARG, "null argument");
     int dev0 = 0;
     if (!devices || n_devices <= 0) { devices = &dev0; n_devices = 1; }
-    std::vector<uint64_t> pair((size_t)N * N, 0), part((size_t)N * N);
-    // address range split into n_devices contiguous slices (multiples of 32 addresses)
-    uint64_t per = ((n + n_devices - 1) / n_devices + 31u) & ~31ULL;
-    for (int d = 0; d < n_devices; d++) {
-        uint64_t lo = std::min<uint64_t>(n, per * d), hi = std::min<uint64_t>(n, lo + per);
-        if (hi <= lo) continue;
-        HIPCHK(hipSetDevice(devices[d]));
-        std::vector<void *> dptr(N, nullptr);
-        rc = PK_OK;
-        for (int i = 0; i < N && !rc; i++) {
-            if (hipMalloc(&dptr[i], hi - lo + 32) != hipSuccess) { rc = fail(PK_ERR_HIP, "hipMalloc(table slice) failed"); break; }
-            if (hipMemcpy(dptr[i], tables[i] + lo, hi - lo, hipMemcpyHostToDevice) != hipSuccess) rc = fail(PK_ERR_HIP, "table upload failed");
-        }
-        if (!rc) rc = pk_gram_device_partial((const void *const *)dptr.data(), N, hi - lo, min_count, max_count, part.data(), nullptr, devices[d], nullptr);
-        for (auto p : dptr) hipFree(p);
-        if (rc) return rc;
-        for (size_t i = 0; i < pair.size(); i++) pair[i] += part[i];
+    // address range split into n_devices contiguous slices (multiples of 32 addresses); one host thread per
+    // device stages its slice and scans it, all devices at once
+    const uint64_t per = ((n + n_devices - 1) / n_devices + 31u) & ~31ULL;
+    std::vector<std::vector<uint64_t>> parts(n_devices, std::vector<uint64_t>((size_t)N * N, 0));
+    std::vector<int> rcs(n_devices, PK_OK);
+    std::vector<std::string> errs(n_devices);
+    auto work = [&](int d) {
+        const uint64_t lo = std::min<uint64_t>(n, per * d), hi = std::min<uint64_t>(n, lo + per);
+        if (hi <= lo) return;
+        auto run = [&]() -> int {
+            HIPCHK(hipSetDevice(devices[d]));
+            // as many tables' slices as fit beside each other in free HBM; the rest in further rounds over
+            // sub-slices of the address range (partials add)
+            size_t free_b = 0, total_b = 0;
+            HIPCHK(hipMemGetInfo(&free_b, &total_b));
+            uint64_t sub = hi - lo;
+            const uint64_t budget = (uint64_t)(free_b * 0.8);
+            if ((uint64_t)N * (sub + 64) > budget) sub = std::max<uint64_t>(1 << 20, (budget / N - 64) & ~2047ULL);
+            std::vector<void *> dptr(N, nullptr);
+            int r = PK_OK;
+            for (int i = 0; i < N && !r; i++)
+                if (hipMalloc(&dptr[i], std::min(sub, hi - lo) + 64) != hipSuccess) r = fail(PK_ERR_HIP, "hipMalloc(table slice) failed");
+            std::vector<uint64_t> one((size_t)N * N);
+            for (uint64_t a = lo; a < hi && !r; a += sub) {
+                const uint64_t b = std::min(hi, a + sub);
+                for (int i = 0; i < N && !r; i++)
+                    if (hipMemcpy(dptr[i], tables[i] + a, b - a, hipMemcpyHostToDevice) != hipSuccess) r = fail(PK_ERR_HIP, "table upload failed");
+                if (!r) r = pk_gram_device_partial((const void *const *)dptr.data(), N, b - a, min_count, max_count, one.data(), nullptr, devices[d], nullptr);
+                if (!r) for (size_t i = 0; i < one.size(); i++) parts[d][i] += one[i];
+            }
+            for (auto p : dptr) hipFree(p);
+            return r;
+        };
+        rcs[d] = run();
+        if (rcs[d]) errs[d] = g_err;                       // g_err is thread-local: carry the message back
+    };
+    if (n_devices == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int d = 0; d < n_devices; d++) th.emplace_back(work, d);
+        for (auto &t : th) t.join();
     }
+    for (int d = 0; d < n_devices; d++)
+        if (rcs[d]) { g_err = errs[d]; return rcs[d]; }
+    std::vector<uint64_t> pair((size_t)N * N, 0);
+    for (int d = 0; d < n_devices; d++)
+        for (size_t i = 0; i < pair.size(); i++) pair[i] += parts[d][i];
     return pk_gram_expand(pair.data(), N, matrix_out);
 }

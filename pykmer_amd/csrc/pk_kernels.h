@@ -59,8 +59,8 @@ int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, co
 
 // gram_scan.hip
 // tables: device array of N device pointers, each n_slice bytes (16-byte aligned).  pair: device N*N u64,
-// zeroed by the launcher; [i][i] += total_i, [i][j] (i<j) += shared_ij.
+// zeroed by the launcher when zero_first; [i][i] += total_i, [i][j] (i<j) += shared_ij.
 int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int min_count, int max_count,
-                unsigned long long *dev_pair, hipStream_t s);
+                unsigned long long *dev_pair, bool zero_first, hipStream_t s);
 
 }  // namespace pk

@@ -332,6 +332,25 @@ class Header(HeaderVars):
         assert table.size == self.data_size, f"{path}: {table.size} bytes, expected {self.data_size}"
         return table
 
+    def read_table_slice(self, lo: int, hi: int, index_file: str = None) -> np.ndarray:
+        """Table bytes [lo, hi) only: a rank of the address-range-sharded merge never touches the rest of the
+        file.  Raw .kin: one positioned read.  BGZF .kin.bgz: only the blocks that cover the slice are
+        inflated.  Plain gzip (what tools.py:300-302 reads through gzip.open) has no random access: the
+        stream is inflated up to `hi` and the front discarded.  `bytes_delivered` counts what came out of
+        the reader, for the tests that check a rank reads its share only."""
+        assert 0 <= lo <= hi <= self.data_size
+        path = index_file or self.index_file
+        if path.endswith(".bgz"):
+            from . import bgzf
+            part, delivered = bgzf.decompress_range(path, lo, hi)
+        else:
+            assert os.path.getsize(path) == self.data_size, f"{path}: not {self.data_size} bytes"
+            part = np.fromfile(path, dtype=np.uint8, count=hi - lo, offset=lo)
+            delivered = part.size
+        assert part.size == hi - lo, f"{path}: short read"
+        self.bytes_delivered = getattr(self, "bytes_delivered", 0) + delivered
+        return part
+
     def get_array_from_fhd(self, fhd: BinaryIO, mode: str = "r+") -> Iterator[np.memmap]:
         yield np.memmap(fhd, dtype=np.uint8, mode=mode, offset=0, shape=(self.data_size,))
 

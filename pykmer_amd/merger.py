@@ -73,54 +73,87 @@ def address_slice(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(n, lo + per)
 
 
-def gpu_partial(headers: List[Header], lo: int, hi: int, windows, device: int, threads: int) -> List[np.ndarray]:
-    """Stage addresses [lo, hi) of every table in HBM on `device` ONCE and tally them with one kernel pass
-    per (min_count, max_count) window."""
-    N = len(headers)
-    bufs = [_lib.DeviceBuffer(hi - lo, device) for _ in range(N)]
+def _sub_slices(lo: int, hi: int, n_tables: int, device: int):
+    """[lo, hi) cut so that n_tables slices fit HBM beside each other (the reference streams pairs and takes
+    any N, merger.py:139-153; here a k=17 merge of 32 tables is 512 GiB).  Partials add, so the cuts are free.
+    PK_MERGE_HBM_BUDGET (bytes) overrides the 80 % of free HBM used by default."""
+    budget = int(os.environ.get("PK_MERGE_HBM_BUDGET", "0")) or int(_lib.mem_info(device)[0] * 0.8)
+    per_table = max(2048, (budget // max(1, n_tables) - 64) & ~2047)
+    return [(a, min(hi, a + per_table)) for a in range(lo, hi, per_table)]
 
-    def stage(i):
-        table = headers[i].read_table()                       # read / inflate on a host thread (GIL released in I/O and zlib)
-        bufs[i].upload(table[lo:hi])
+
+def gpu_partial(headers: List[Header], lo: int, hi: int, windows, device: int, threads: int, acc_ptr: int = None):
+    """Stage addresses [lo, hi) of every table in HBM on `device` (sub-slice by sub-slice if they do not all
+    fit) and tally each staged piece with one kernel pass per (min_count, max_count) window.  Only bytes
+    [lo, hi) of each file are read / inflated.  The tallies are accumulated in HBM: at `acc_ptr` (W x N x N u64,
+    zeroed by the caller -- the buffer an RCCL all-reduce then sums) or in a buffer of this call, which is
+    then returned as W host arrays."""
+    N, W = len(headers), len(windows)
+    own = None
+    if acc_ptr is None:
+        own = _lib.DeviceBuffer(W * N * N * 8, device)
+        own.zero()
+        acc_ptr = own.ptr
+    cuts = _sub_slices(lo, hi, N, device)
+    bufs = [_lib.DeviceBuffer(max(b - a for a, b in cuts), device) for _ in range(N)]
     try:
         with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
-            list(pool.map(stage, range(N)))
-        parts = [_lib.gram_device_partial([b.ptr for b in bufs], hi - lo, mn, mx, device=device)[0] for mn, mx in windows]
+            for a, b in cuts:
+                # read / inflate on host threads (GIL released in I/O and zlib), upload as each one lands
+                list(pool.map(lambda i: bufs[i].upload(headers[i].read_table_slice(a, b)), range(N)))
+                for w, (mn, mx) in enumerate(windows):
+                    _lib.gram_device_accumulate([buf.ptr for buf in bufs], b - a, acc_ptr + w * N * N * 8, mn, mx, device=device)
+        if own is None:
+            return None
+        return list(own.download().view(np.uint64).reshape(W, N, N))
     finally:
-        for b in bufs:
-            b.free()
-    return parts
+        for buf in bufs:
+            buf.free()
+        if own is not None:
+            own.free()
 
 
 def pair_matrix(headers: List[Header], windows, threads: int = DEFAULT_THREADS, devices=(0,), group=None,
                 partial_fn=gpu_partial) -> List[np.ndarray]:
     """One N x N u64 per (min, max) window: [i][i] = valid addresses of table i, [i][j] (i<j) = addresses valid in both.
 
-    Single process: the address range is split over `devices`.  With `group` (a torch.distributed
-    process group, or True for the default group) this rank scans only its own slice on devices[0]
-    and the partials of all windows are summed by ONE all-reduce.  `partial_fn` computes one slice's
-    tallies (the GPU path above; the CPU-only distributed tests substitute the oracle)."""
+    Single process: the address range is split over `devices`, one host thread per device.  With `group`
+    (a torch.distributed process group, or True for the default group) this rank scans only its own slice
+    on devices[0] and the partials of all windows are summed by ONE all-reduce -- over RCCL on the
+    accumulator where the kernel left it in HBM.  `partial_fn` computes one slice's tallies (the GPU path
+    above; the CPU-only tests substitute the oracle)."""
     n, N, W = headers[0].data_size, len(headers), len(windows)
-    if group is not None:
-        import torch.distributed as dist
-        pg = None if group is True else group
-        plan = [(devices[0],) + address_slice(n, dist.get_rank(pg), dist.get_world_size(pg))]
-    else:
+    if group is None:
         plan = [(d,) + address_slice(n, i, len(devices)) for i, d in enumerate(devices)]
-    total = np.zeros((W, N, N), dtype=np.uint64)
-    for dev, lo, hi in plan:
+        plan = [p for p in plan if p[2] > p[1]]
+        with ThreadPoolExecutor(max_workers=max(1, len(plan))) as pool:
+            parts = list(pool.map(lambda p: partial_fn(headers, p[1], p[2], windows, p[0], max(1, threads // len(plan))), plan))
+        total = np.zeros((W, N, N), dtype=np.uint64)
+        for part in parts:
+            for w in range(W):
+                total[w] += part[w]
+        return [total[w] for w in range(W)]
+
+    import torch
+    import torch.distributed as dist
+    pg = None if group is True else group
+    dev = devices[0]
+    lo, hi = address_slice(n, dist.get_rank(pg), dist.get_world_size(pg))
+    if partial_fn is gpu_partial and dist.get_backend(pg) == "nccl":
+        acc = torch.zeros((W, N, N), dtype=torch.int64, device=torch.device("cuda", dev))
+        torch.cuda.synchronize(dev)                             # zeroed before the scan (its own stream) adds to it
+        if hi > lo:
+            gpu_partial(headers, lo, hi, windows, dev, threads, acc_ptr=acc.data_ptr())
+        dist.all_reduce(acc, group=pg)                         # RCCL over xGMI: W x N x N u64, a few KB
+        total = acc.cpu().numpy().view(np.uint64)
+    else:
+        total = np.zeros((W, N, N), dtype=np.uint64)
         if hi > lo:
             for w, part in enumerate(partial_fn(headers, lo, hi, windows, dev, threads)):
                 total[w] += part
-    if group is not None:
-        import torch
-        import torch.distributed as dist
-        pg = None if group is True else group
         t = torch.from_numpy(total.view(np.int64).copy())
-        if dist.get_backend(pg) == "nccl":
-            t = t.to(torch.device("cuda", devices[0]))
-        dist.all_reduce(t, group=pg)                           # sum of the N x N partials (RCCL over xGMI on GPUs)
-        total = t.cpu().numpy().view(np.uint64)
+        dist.all_reduce(t, group=pg)
+        total = t.numpy().view(np.uint64)
     return [total[w] for w in range(W)]
 
 

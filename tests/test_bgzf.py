@@ -88,3 +88,29 @@ def test_header_reads_bgzf_table_and_cli(tmp_path, manifest):
     h = Header(path + ".bgz", index_file=path + ".bgz")
     assert h.index_file.endswith(".bgz") and np.array_equal(h.read_table(), want)
     assert bytes(list(h)[:100]) == want[:100].tobytes()              # Header.__iter__ streams the same bytes (tools.py:527-533)
+
+
+def test_decompress_range_reads_only_covering_blocks(tmp_path):
+    """Address-range-sharded merge: a rank inflates only the BGZF blocks that cover its slice, located through
+    the .gzi (gzireader.py:12-34 layout) or, without one, by walking the block headers; plain gzip streams
+    (what the reference's own tests call .bgz, tools.py:300-302) are read sequentially up to the slice end."""
+    import gzip
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 4, size=1_000_000, dtype=np.uint8)
+    src = tmp_path / "t.kin"
+    data.tofile(src)
+    dst, gzi = bgzf.compress_file(str(src), level=1, threads=2)
+    n_blocks = (data.size + bgzf.BLOCK_INPUT - 1) // bgzf.BLOCK_INPUT
+    for use_gzi in (True, False):
+        if not use_gzi:
+            os.remove(gzi)
+        for lo, hi in ((0, 10), (0, data.size), (65279, 65281), (200_000, 700_001), (data.size - 5, data.size), (123, 123)):
+            part, inflated = bgzf.decompress_range(dst, lo, hi, threads=2)
+            assert np.array_equal(part, data[lo:hi]), (use_gzi, lo, hi)
+            covering = 0 if hi == lo else (hi - 1) // bgzf.BLOCK_INPUT - lo // bgzf.BLOCK_INPUT + 1
+            assert inflated <= covering * bgzf.BLOCK_INPUT and covering <= n_blocks
+    plain = tmp_path / "p.kin.bgz"
+    with gzip.open(plain, "wb") as fh:
+        fh.write(data.tobytes())
+    part, inflated = bgzf.decompress_range(str(plain), 300_000, 300_100)
+    assert np.array_equal(part, data[300_000:300_100]) and inflated == 300_100

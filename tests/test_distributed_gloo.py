@@ -32,8 +32,9 @@ def _worker(rank, world, port, workdir, paths, mn, mx):
         seen = []
 
         def partial(headers, lo, hi, *a):
-            seen.append((lo, hi))
-            return _oracle_partial(headers, lo, hi, *a)              # (windows, device, threads) pass through
+            out = _oracle_partial(headers, lo, hi, *a)               # (windows, device, threads) pass through
+            seen.append((lo, hi, sum(h.bytes_delivered for h in headers)))
+            return out
         data, matrix = merger.merge(os.path.join(workdir, "dist"), paths, min_count=mn, max_count=mx, group=True, partial_fn=partial)
         np.save(os.path.join(workdir, f"matrix_rank{rank}.npy"), matrix)
         np.save(os.path.join(workdir, f"slice_rank{rank}.npy"), np.array(seen))
@@ -52,7 +53,10 @@ def test_sharded_merge_matches_reference_matrix(tmp_path, manifest, world):
     slices = []
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"matrix_rank{r}.npy"), want)       # every rank holds the reduced matrix
-        slices.append(tuple(np.load(tmp_path / f"slice_rank{r}.npy")[0]))
+        lo, hi, delivered = (int(v) for v in np.load(tmp_path / f"slice_rank{r}.npy")[0])
+        slices.append((lo, hi))
+        # each rank read only its share of every table: N * 4^k / world bytes (+ rounding to 32 addresses)
+        assert delivered == len(paths) * (hi - lo) <= len(paths) * (4 ** 7 // world + 32)
     assert slices[0][0] == 0 and slices[-1][1] == 4 ** 7                             # disjoint cover of the address range
     assert all(a[1] == b[0] for a, b in zip(slices[:-1], slices[1:]))
     kma = np.load(tmp_path / "dist.002-255.kma")["matrix"]                           # written once, by rank 0

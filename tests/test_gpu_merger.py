@@ -105,3 +105,94 @@ def test_gram_full_size_properties(gpu):
     b = (tabs[1] >= 3) & (tabs[1] <= 200)
     assert int(p2[0, 0]) == int(a.sum().item()) and int(p2[0, 1]) == int((a & b).sum().item())
     print(f"gram N=13 k=15 kernel {secs * 1e3:.3f} ms -> {N * n / secs / 1e12:.2f} TB/s")
+
+
+def _torch_tables(n, N, seed):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    tabs = []
+    for i in range(N):
+        t = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda", generator=g)
+        keep = torch.rand(n, device="cuda", generator=g) < (0.1 + 0.8 * ((i * 7) % N) / N)
+        tabs.append(t * keep)
+    torch.cuda.synchronize()
+    return tabs
+
+
+@pytest.mark.parametrize("N", [13, 32])
+def test_gram_full_size_every_pair(gpu, N):
+    """configs 3 and 5 at full size (4^15-byte tables resident in HBM): EVERY total and EVERY shared tally
+    against an independent torch computation, default window and a --min/--max window."""
+    import torch
+    torch.cuda.empty_cache()
+    n = 4 ** 15
+    tabs = _torch_tables(n, N, seed=40 + N)
+    ptrs = [t.data_ptr() for t in tabs]
+    for mn, mx in ((1, 255), (3, 200)):
+        pair, secs = gpu.gram_device_partial(ptrs, n, mn, mx)
+        valid = [(t >= mn) & (t <= mx) for t in tabs]
+        for i in range(N):
+            assert int(pair[i, i]) == int(valid[i].sum().item()), (N, mn, mx, i)
+            for j in range(i + 1, N):
+                assert int(pair[i, j]) == int((valid[i] & valid[j]).sum().item()), (N, mn, mx, i, j)
+            assert not pair[i, :i].any()
+        del valid
+    print(f"gram N={N} k=15 kernel {secs * 1e3:.3f} ms -> {N * n / secs / 1e12:.2f} TB/s")
+    del tabs
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("N,log4n", [(48, 15), (64, 15), (41, 16)])
+def test_gram_packed_tallies_worst_case_at_size(gpu, N, log4n):
+    """The 16-bit packed tallies (N 41-48, and every launch of N > 48) at the sizes that matter, with DENSE
+    tables -- every address valid is the worst case for a tally that must not carry into its neighbour.
+    4^15: 128 tiles per workgroup; 4^16 with N = 41: more than 448 tiles per workgroup at the default grid,
+    so the launcher's grid-resize branch runs.  Expected values are closed-form: a table whose constant
+    value lies inside the window is valid everywhere, so totals and shared tallies are n or 0."""
+    import torch
+    torch.cuda.empty_cache()
+    n = 4 ** log4n
+    values = [(i % 5) + 1 for i in range(N)]                         # table i holds the constant values[i]
+    tabs = [torch.full((n,), v, dtype=torch.uint8, device="cuda") for v in values]
+    torch.cuda.synchronize()
+    ptrs = [t.data_ptr() for t in tabs]
+    for mn, mx in ((1, 255), (2, 4)):
+        pair, secs = gpu.gram_device_partial(ptrs, n, mn, mx)
+        ok = [mn <= v <= mx for v in values]
+        want = np.zeros((N, N), dtype=np.uint64)
+        for i in range(N):
+            for j in range(i, N):
+                want[i, j] = n if ok[i] and ok[j] else 0
+        assert np.array_equal(pair, want), (N, log4n, mn, mx)
+    print(f"gram N={N} n=4^{log4n} dense: kernel {secs * 1e3:.2f} ms -> {N * n / secs / 1e12:.2f} TB/s")
+    del tabs
+    torch.cuda.empty_cache()
+
+
+def test_merge_host_path_sub_slices_and_threads(gpu, tmp_path, monkeypatch):
+    """merger.pair_matrix on real files: a small HBM budget forces several sub-slices per device slice
+    (partials accumulate in HBM), two host threads drive two plan entries on the same GPU at once, one
+    table arrives as BGZF with a .gzi -- and only the bytes of each slice are read."""
+    from pykmer_amd import bgzf, merger
+    from pykmer_amd.header import Header
+    from test_host_layer import _write_index
+    import synth
+    k, N = 9, 5
+    paths, tables = [], []
+    for i in range(N):
+        fa, _ = synth.family(i, 60_000)
+        h, got = _write_index(tmp_path, f"m{i}.fa", fa.tobytes(), k)
+        paths.append(h.index_file_root)
+        tables.append(got["table"])
+    bgzf.compress_file(paths[2], level=1)
+    headers = [Header(p, index_file=p) for p in paths]
+    assert headers[2].index_file.endswith(".bgz")
+    monkeypatch.setenv("PK_MERGE_HBM_BUDGET", str(N * (40_000 + 64)))
+    assert len(merger._sub_slices(0, 4 ** k // 2, N, 0)) >= 3
+    windows = [(1, 255), (2, 9)]
+    got = merger.pair_matrix(headers, windows, threads=4, devices=(0, 0))
+    for (mn, mx), pair in zip(windows, got):
+        assert np.array_equal(gpu.gram_expand(pair), oracle.gram(tables, mn, mx)), (mn, mx)
+    raw = [h.bytes_delivered for i, h in enumerate(headers) if i != 2]
+    assert all(b == 4 ** k for b in raw)                                # every byte of a raw table exactly once
+    assert headers[2].bytes_delivered <= 4 ** k + 2 * len(merger._sub_slices(0, 4 ** k // 2, N, 0)) * bgzf.BLOCK_INPUT

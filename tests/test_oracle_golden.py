@@ -163,3 +163,17 @@ def test_all_cores_port_equals_scalar_port(threads):
 
 def test_all_cores_port_declines_blanks_in_sequence_lines():
     assert oracle.count_fasta_mt(inputs.edge_fasta(), 7, 4) is None          # interior / leading blanks: scalar port only
+
+
+def test_gram_mt_equals_scalar_gram():
+    """bench.py's all-cores merge baseline (pair loop on a thread pool, merger.py:137-153) gives the scalar port's matrix."""
+    rng = np.random.default_rng(31)
+    tables = []
+    for _ in range(6):
+        t = rng.integers(0, 8, size=40_000, dtype=np.uint8)
+        t[rng.random(t.size) < 0.5] = 0
+        tables.append(t)
+    for mn, mx in ((1, 255), (2, 5)):
+        want = oracle.gram(tables, mn, mx)
+        for threads in (1, 3):
+            assert np.array_equal(oracle.gram_mt(tables, mn, mx, threads), want)
