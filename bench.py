@@ -137,13 +137,15 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    count_s = scan_s = final_s = zero_s = part_s = bucket_s = 0.0
+    acc = {"scan_s": 0.0, "squeeze_s": 0.0, "walk_sort_s": 0.0, "partition_s": 0.0, "bucket_s": 0.0, "finalize_s": 0.0, "zero_s": 0.0}
+    relayouts = 0
     fin = None
     for _ in range(args.steps):
         fin = step()
         t = ix.timings()
-        count_s += t["count_s"]; scan_s += t["scan_s"]; final_s += t["finalize_s"]; zero_s += t["zero_s"]
-        part_s += t["partition_s"]; bucket_s += t["bucket_s"]
+        for key in acc:
+            acc[key] += t[key]
+        relayouts += t["relayouts"]
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -157,23 +159,28 @@ def main():
         bp_job = total_bp
     assert fin["total_bp"] == total_bp, (fin["total_bp"], total_bp)
     value = bp_job * args.steps / elapsed
+    avg = {key: v / args.steps for key, v in acc.items()}
 
-    # ---- roofline of the dominant kernel (the k-mer walk: k_walk_flat, or k_count in direct mode).
-    # Algorithmic bytes = FASTA read once + table written once (F + 4^k, 2.36 B/bp on C2 at k=15);
-    # duration = that kernel's launches timed with HIP events on the indexer's stream (pk_indexer_timings).
+    # ---- roofline of the dominant kernel: k_walk_sort (packed bases -> canonical k-mers -> level-1 runs), or
+    # k_bucket_count where writing the table dominates (k=17).  Algorithmic bytes = FASTA read once + table written
+    # once (F + 4^k, 2.36 B/bp on C2 at k=15); duration = that kernel's launches timed with HIP events on
+    # the indexer's own stream (pk_indexer_timings).
     alg_bytes = n_bytes + 4 ** k
-    walk_avg = count_avg = count_s / args.steps
-    dominant = "k_count" if t["direct"] else "k_walk_flat"
-    if not t["direct"] and bucket_s > count_s:                     # large tables (k=17): writing the table dominates
-        dominant, count_avg = "k_bucket_count", bucket_s / args.steps
-    achieved = alg_bytes / count_avg / 1e9
-    traffic = pipeline_traffic = None
+    dominant, dom_avg = "k_walk_sort", avg["walk_sort_s"]
+    if avg["bucket_s"] > dom_avg:
+        dominant, dom_avg = "k_bucket_count", avg["bucket_s"]
+    achieved = alg_bytes / dom_avg / 1e9
+    # measured HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from inside the
+    # process): tools/hbm_traffic.py turns the two CSVs into profiles/hbm_traffic.json, collected on exactly this workload
+    traffic = pipeline_traffic = traffic_source = None
     tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tp) and k == 15 and args.bp == 800_000_000:  # PMC bytes were collected on exactly this workload
+    if os.path.exists(tp) and k == 15 and args.bp == 800_000_000:
         with open(tp) as fh:
             tj = json.load(fh)
-        traffic = tj.get(dominant, {}).get("bytes_per_launch")
-        pipeline_traffic = tj.get("_pipeline_bytes_per_step")
+        if dominant in tj:
+            traffic = tj[dominant].get("bytes_per_launch")
+            pipeline_traffic = tj.get("_pipeline_bytes_per_step")
+            traffic_source = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run)"
     out = {
         "metric": f"bp/s k-mer counted (k={k}, {world} GPU{'s' if world > 1 else ''})",
         "value": value, "unit": "bp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -183,14 +190,16 @@ def main():
                                f"(SURVEY 8d C2, seed 2+rank), 4^{k} table resident in HBM",
                    "fasta_bytes": n_bytes, "num_kmers": fin["num_kmers"], "parallelism": f"{world} independent genome(s)"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": count_avg * 1e3,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_avg * 1e3,
                      "pipeline_traffic_bytes_per_step": pipeline_traffic,
                      "pipeline_hbm_GBps": (pipeline_traffic / (elapsed / args.steps) / 1e9) if pipeline_traffic else None},
-        "stage_ms": {"zero_table": zero_s / args.steps * 1e3, "structure_scans": scan_s / args.steps * 1e3,
-                     "walk_kernel": walk_avg * 1e3, "partition_passes": part_s / args.steps * 1e3,
-                     "bucket_count": bucket_s / args.steps * 1e3, "histogram": final_s / args.steps * 1e3,
-                     "mode": "direct" if t["direct"] else "partitioned"},
+        "stage_ms": {"reset": avg["zero_s"] * 1e3, "structure_scans": avg["scan_s"] * 1e3, "squeeze": avg["squeeze_s"] * 1e3,
+                     "walk_sort_kernel": avg["walk_sort_s"] * 1e3,
+                     "bucket_layout_and_level2": (avg["partition_s"] - avg["walk_sort_s"]) * 1e3,
+                     "bucket_count": avg["bucket_s"] * 1e3, "finish": avg["finalize_s"] * 1e3,
+                     "bucket_relayouts": relayouts},
+        "t_kernel_s": elapsed / args.steps,
     }
 
     # ---- secondary: N x N merge scan over N tables resident in HBM, address range sharded over ranks

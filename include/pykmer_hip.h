@@ -53,8 +53,6 @@ int pk_dev_mem_info(uint64_t *free_out, uint64_t *total_out, int device);
 
 /* ---- indexer: replaces gen_kmers + canonical min + process_kmers (indexer.py:130-160, 341, 162-297)
  * and the parser that feeds them (indexer.py:45-99).  k must be odd, 1 <= k <= 17 (tools.py:165-167).
- * Environment: PK_COUNT_MODE=direct selects the version-1 table update (one global atomic per k-mer on
- * u32 counters) instead of the default partitioned one; results are identical.
  *
  * fasta       uncompressed FASTA text (what gzip.open(...,'rt') would hand the reference)
  * table_out   4^k bytes (host); receives table[a] = min(255, #canonical k-mers with value a): the
@@ -73,8 +71,8 @@ int pk_indexer_create(pk_indexer **out, int k, int device);
 int pk_indexer_reset(pk_indexer *ix);                       /* zero the table, forget parser state  */
 /* Feed the next n_bytes of the FASTA text.  Chunks may split lines, records and k-mers anywhere.   */
 int pk_indexer_feed(pk_indexer *ix, const uint8_t *host_fasta, uint64_t n_bytes);
-/* Same, but the bytes already sit in device memory on the indexer's device (16-byte aligned, < 4 GiB per
- * call).  Work runs on the indexer's own stream; the call returns when the feed has been counted. */
+/* Same, but the bytes already sit in device memory on the indexer's device (16-byte aligned).  Work runs on
+ * the indexer's own stream; the call returns when the feed has been counted. */
 int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uint64_t n_bytes);
 /* Close the last record and report the totals.  hist256_out[v] = number of table entries equal to v
  * (the histogram is kept in HBM while counting, so this makes no pass over the table).              */
@@ -89,10 +87,11 @@ int pk_indexer_table_device(pk_indexer *ix, const void **dev_table_out);
  * address-range slice for a sharded merge while the indexer goes on to the next sample). */
 int pk_indexer_table_slice_to_device(pk_indexer *ix, void *dev_dst, uint64_t offset, uint64_t n_bytes);
 /* Seconds spent since the last reset per stage, measured with HIP events on the indexer's stream:
- * [0] structure scans, [1] k-mer walk kernel (extract + route; in direct mode extract + atomic count),
- * [2] finish (direct mode: clamp+histogram pass; otherwise next to nothing), [3] table zeroing, [4] feeds (as a double),
- * [5] partition passes, [6] bucket count + side list, [7] 1.0 if PK_COUNT_MODE=direct. */
-int pk_indexer_timings(pk_indexer *ix, double out[8]);
+ * [0] structure scans, [1] squeeze pass (text -> packed bases + record tallies), [2] finish, [3] reset,
+ * [4] feeds (as a double), [5] everything between squeeze and bucket count (bucket layout, fused k-mer
+ * assembly + level-1 sort, level 2), [6] bucket count + histogram rows + side list, [7] of [5]: the fused
+ * k_walk_sort kernel alone, [8] how many feeds had to be laid out a second time with exact bucket sizes. */
+int pk_indexer_timings(pk_indexer *ix, double out[10]);
 void pk_indexer_destroy(pk_indexer *ix);
 
 /* ---- stats: replaces Header.update_stats (tools.py:246-263) on a host table of n bytes. */

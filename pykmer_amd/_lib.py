@@ -216,10 +216,10 @@ class Indexer:
         _check(load().pk_indexer_table_slice_to_device(self._h, ctypes.c_void_p(dev_dst), offset, n_bytes))
 
     def timings(self) -> dict:
-        t = np.zeros(8, dtype=np.float64)
+        t = np.zeros(10, dtype=np.float64)
         _check(load().pk_indexer_timings(self._h, t.ctypes.data))
-        return {"scan_s": t[0], "count_s": t[1], "finalize_s": t[2], "zero_s": t[3], "count_launches": int(t[4]),
-                "partition_s": t[5], "bucket_s": t[6], "direct": bool(t[7])}
+        return {"scan_s": t[0], "squeeze_s": t[1], "finalize_s": t[2], "zero_s": t[3], "feeds": int(t[4]),
+                "partition_s": t[5], "bucket_s": t[6], "walk_sort_s": t[7], "relayouts": int(t[8])}
 
 
 def count_fasta(data, k: int, device: int = 0, table_out: np.ndarray = None):

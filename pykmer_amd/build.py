@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpykmer_hip.so")
-SOURCES = ["kmer_count.hip", "kmer_part.hip", "gram_scan.hip", "pk_api.hip"]
+SOURCES = ["kmer_count.hip", "kmer_pack.hip", "kmer_fuse.hip", "kmer_part.hip", "gram_scan.hip", "pk_api.hip"]
 
 
 def _deps():

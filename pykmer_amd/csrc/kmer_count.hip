@@ -1,17 +1,10 @@
-// kmer_count.hip -- indexer kernels for gfx950: FASTA structure scans, the fused
-// 2-bit-encode / rolling canonical k-mer / table-increment kernel, and the clamp+histogram pass.
+// kmer_count.hip -- the structure pass of the indexer for gfx950 and the table histogram.
 //
-// Replaces, in the reference: parse_fasta (indexer.py:45-99), gen_kmers (indexer.py:130-160), the
-// canonical min (indexer.py:341), process_kmers (indexer.py:162-297) and Header.update_stats
-// (tools.py:246-263).  See fasta_fsm.h for how the sequential parser is made data-parallel.
-//
-// Table update, version 1 ("direct"): the 4^k counters live in HBM as u32 (4 GiB at k=15, 64 GiB at
-// k=17 -- both resident in 288 GB), every lane run-length-merges consecutive identical canonical
-// k-mers (homopolymers, (AT)n: the contended buckets) and issues one no-return
-// global_atomic_add_u32 per run; k_finalize then clamps to u8, which is exact because the reference
-// only ever keeps min(255, count) (indexer.py:239,262).
+// Structure pass: makes the reference's line-by-line parser (parse_fasta, indexer.py:45-99) data-parallel.
+// Every 64-byte piece of text is summarised, the summaries are composed in prefix scans (see
+// fasta_fsm.h), and every piece gets its exact parser state -- what the squeeze pass (kmer_pack.hip)
+// starts from.  k_hist is Header.update_stats (tools.py:246-263) for tables that arrive from disk.
 #include "fasta_fsm.h"
-#include "kmer_walk.h"
 #include "pk_kernels.h"
 
 namespace pk {
@@ -186,70 +179,11 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_l2_apply(const L2 *__restrict__
     if (i < n) out_state[i] = ex;
 }
 
-// ------------------------------------------------------------------ k-mer walk -----------------
-// Sink for table update v1: u32 counters in HBM, per-lane run-length merge, no-return atomics.
-struct DirectSink {
-    uint32_t *table;
-    uint64_t last;
-    uint32_t cnt;
-    __device__ __forceinline__ void init(uint32_t *t) { table = t; last = 0; cnt = 0; }
-    __device__ __forceinline__ void emit(uint64_t a) {
-        if (cnt && a == last) { cnt++; return; }
-        if (cnt) __hip_atomic_fetch_add(table + last, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = a; cnt = 1;
-    }
-    __device__ __forceinline__ void flush() {
-        if (cnt) __hip_atomic_fetch_add(table + last, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cnt = 0;
-    }
-};
-
-template <typename KT>
-__global__ __launch_bounds__(WG) void k_count(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
-                                              const LaneState *__restrict__ lane_state, const L2 *__restrict__ chunk_l2_state,
-                                              uint32_t k, uint32_t *__restrict__ table32, DevRec *__restrict__ recs,
-                                              uint64_t recs_cap, Carry *carry) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[WG * LDS_STRIDE];
-    __shared__ RecAcc racc;
-    const uint32_t km1 = k - 1;
-    uint64_t base = (uint64_t)blockIdx.x * CHUNK;
-    recacc_init(racc);
-    stage_chunk(fasta, base, n_bytes, lds);
-    __syncthreads();
-    recacc_retarget(racc, chunk_l2_state[blockIdx.x].rec, recs, recs_cap);
-    __syncthreads();
-    const uint32_t nb = piece_len(base, n_bytes);
-    // exact parser state at this lane's first byte: chunk state . lane prefix (from k_chunk_l2)
-    const LaneState lst = lane_state[(uint64_t)blockIdx.x * WG + threadIdx.x];
-    const L2 st2 = l2_compose(chunk_l2_state[blockIdx.x], lane_state_l2(lst), km1);
-    const uint32_t ls = lane_state_ls(lst);
-    Walker<KT> wk;
-    wk.setup(k, recs, recs_cap, &racc);
-    wk.begin(ls, st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
-    DirectSink sink;
-    sink.init(table32);
-    if (__all(!lane_state_dirty(lst) && ls != LS_HEADER && st2.p_tail == 0)) {
-        wk.walk_clean(lds, nb, [&](bool has, KT canon) { if (has) sink.emit((uint64_t)canon); });
-    } else {
-        for_each_byte(lds, nb, [&](uint32_t i, uint32_t c, bool act) {
-            KT canon;
-            if (wk.step(i, c, act, canon)) sink.emit((uint64_t)canon);
-        });
-    }
-    sink.flush();
-    wk.flush_rec_wave();
-    wk.finish();
-    recacc_finish(racc, recs, recs_cap, carry);
-}
-
-// ------------------------------------------------------------------ clamp + histogram ----------
-// SRC32: read u32 counters, write min(255, x) as u8 (16 per lane, one dwordx4 store) and count the
-// 256 values; !SRC32: histogram an existing u8 table (Header.update_stats, tools.py:246-263).
-// Zero and one -- by far the commonest values of a k-mer table -- are counted in registers; the rest
-// go through a per-wave LDS histogram so hot bins do not serialise on one LDS address per workgroup.
-template <bool SRC32>
-__global__ __launch_bounds__(WG) void k_hist(const void *__restrict__ src, uint8_t *__restrict__ dst8, uint64_t n,
-                                             unsigned long long *__restrict__ hist /*[256]*/) {
+// ------------------------------------------------------------------ histogram ------------------
+// Histogram of an existing u8 table (Header.update_stats, tools.py:246-263).  Zero and one -- by far the
+// commonest values of a k-mer table -- are counted in registers; the rest go through a per-wave LDS
+// histogram so hot bins do not serialise on one LDS address per workgroup.
+__global__ __launch_bounds__(WG) void k_hist(const uint8_t *__restrict__ src, uint64_t n, unsigned long long *__restrict__ hist /*[256]*/) {
     __shared__ uint32_t h[WG / 64][256];
     for (int i = threadIdx.x; i < (WG / 64) * 256; i += WG) (&h[0][0])[i] = 0;
     __syncthreads();
@@ -257,33 +191,19 @@ __global__ __launch_bounds__(WG) void k_hist(const void *__restrict__ src, uint8
     uint64_t ones = 0;
     const uint64_t n16 = n / 16;
     for (uint64_t g = (uint64_t)blockIdx.x * WG + threadIdx.x; g < n16; g += (uint64_t)gridDim.x * WG) {
-        uint32_t v[16];
-        if (SRC32) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(src) + g * 4;
-            uint4 a = p[0], b = p[1], c = p[2], d = p[3];
-            uint32_t t[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-            uint32_t o[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < 16; j++) { v[j] = t[j] > 255u ? 255u : t[j]; o[j >> 2] |= v[j] << (8 * (j & 3)); }
-            reinterpret_cast<uint4 *>(dst8)[g] = make_uint4(o[0], o[1], o[2], o[3]);
-        } else {
-            uint4 a = reinterpret_cast<const uint4 *>(src)[g];
-            uint32_t t[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-            for (int j = 0; j < 16; j++) v[j] = (t[j >> 2] >> (8 * (j & 3))) & 0xffu;
-        }
+        const uint4 a = reinterpret_cast<const uint4 *>(src)[g];
+        const uint32_t t[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            if (v[j] == 1u) ones++;
-            else if (v[j]) atomicAdd(&myh[v[j]], 1u);
+            const uint32_t v = (t[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            if (v == 1u) ones++;
+            else if (v) atomicAdd(&myh[v], 1u);
         }
     }
     // tail (n not a multiple of 16): first workgroup, one element per lane
     if (blockIdx.x == 0) {
         for (uint64_t i = n16 * 16 + threadIdx.x; i < n; i += WG) {
-            uint32_t x;
-            if (SRC32) { x = reinterpret_cast<const uint32_t *>(src)[i]; x = x > 255u ? 255u : x; dst8[i] = (uint8_t)x; }
-            else x = reinterpret_cast<const uint8_t *>(src)[i];
+            const uint32_t x = src[i];
             if (x == 1u) ones++;
             else if (x) atomicAdd(&myh[x], 1u);
         }
@@ -295,14 +215,6 @@ __global__ __launch_bounds__(WG) void k_hist(const void *__restrict__ src, uint8
         unsigned long long s = 0;
         for (int w = 0; w < WG / 64; w++) s += h[w][b];
         if (s) atomicAdd(&hist[b], s);
-    }
-}
-
-// In-place clamp of the u32 counters (keeps long streams from wrapping 2^32 on one address).
-__global__ __launch_bounds__(WG) void k_clamp32(uint32_t *__restrict__ t, uint64_t n) {
-    for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * WG) {
-        uint32_t x = t[i];
-        if (x > 255u) t[i] = 255u;
     }
 }
 
@@ -327,27 +239,14 @@ void launch_scan_l2(const L2 *in, uint32_t n_chunks, Carry *carry, L2 *out, L2 *
     hipLaunchKernelGGL(k_scan_l2_tiles, dim3(1), dim3(SCAN_T), 0, s, tile_ws, n_tiles, carry, k - 1);
     hipLaunchKernelGGL(k_scan_l2_apply, dim3(n_tiles), dim3(SCAN_T), 0, s, in, n_chunks, (const L2 *)tile_ws, out, k - 1);
 }
-void launch_count(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, uint32_t n_chunks,
-                  uint32_t k, uint32_t *table32, DevRec *recs, uint64_t recs_cap, Carry *carry, hipStream_t s) {
-    if (k <= 15)
-        hipLaunchKernelGGL(k_count<uint32_t>, dim3(n_chunks), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, k, table32, recs, recs_cap, carry);
-    else
-        hipLaunchKernelGGL(k_count<uint64_t>, dim3(n_chunks), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, k, table32, recs, recs_cap, carry);
-}
 static uint32_t stream_grid(uint64_t items_per_thread_units) {
     uint64_t g = (items_per_thread_units + WG - 1) / WG;
     if (g > 256u * 8u) g = 256u * 8u;
     if (g == 0) g = 1;
     return (uint32_t)g;
 }
-void launch_finalize(const uint32_t *table32, uint8_t *table8, uint64_t n, unsigned long long *hist, hipStream_t s) {
-    hipLaunchKernelGGL(k_hist<true>, dim3(stream_grid(n / 16 + 1)), dim3(WG), 0, s, (const void *)table32, table8, n, hist);
-}
 void launch_hist8(const uint8_t *table8, uint64_t n, unsigned long long *hist, hipStream_t s) {
-    hipLaunchKernelGGL(k_hist<false>, dim3(stream_grid(n / 16 + 1)), dim3(WG), 0, s, (const void *)table8, (uint8_t *)nullptr, n, hist);
-}
-void launch_clamp32(uint32_t *table32, uint64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_clamp32, dim3(stream_grid(n)), dim3(WG), 0, s, table32, n);
+    hipLaunchKernelGGL(k_hist, dim3(stream_grid(n / 16 + 1)), dim3(WG), 0, s, table8, n, hist);
 }
 
 }  // namespace pk

@@ -1,0 +1,126 @@
+// kmer_pack.hip -- the squeeze pass: FASTA text -> packed stream of valid bases.
+//
+// The reference turns every record into a tuple of codes (0-3, None) and slides a k-window over it
+// (parse_fasta indexer.py:45-99, gen_kmers :130-160).  Here the text is read once more after the
+// structure pass (kmer_count.hip) has given every 64-byte piece its exact parser state, and what is kept
+// of it is just what the k-mer windows need:
+//
+//   codes    2 bits per VALID base of a record (A 0, C 1, G 2, T 3; CONV, indexer.py:36-41), 16 per dword
+//            from bit 0 up, in text order.  Line terminators, headers, blanks and characters that map to
+//            None are gone;
+//   restart  1 bit per base: the run of valid bases starts anew here (first base of a record, or
+//            something that maps to None lay between it and the base before: indexer.py:144 voids every
+//            window that would span it).
+//
+// Each 16 KiB chunk of text owns a fixed slot (4 KiB of codes, 2 KiB of restart bits, a base count), so no
+// stream-wide compaction is needed: the k-1 bases in front of a slot come from the chunk's start state.
+// Per-record tallies (seq_len, number of valid windows, header extent: indexer.py:75-95,349-351) are
+// taken here too, where the text is in hand.  0.38 bytes written per base instead of one 4-byte record;
+// kmer_fuse.hip assembles the k-mers from the slots with no dependence between its threads.
+#include "fasta_fsm.h"
+#include "kmer_walk.h"
+#include "pk_kernels.h"
+
+namespace pk {
+
+// exclusive scan of a small count over the 256 lanes of the workgroup (sh: 4 words; one barrier)
+__device__ __forceinline__ uint32_t wg_excl_scan_u32(uint32_t v, uint32_t *sh, uint32_t &total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (int i = 0; i < w; i++) pre += sh[i];
+    total = sh[0] + sh[1] + sh[2] + sh[3];
+    return pre + inc - v;
+}
+
+// OR `n_bits` bits of (lo, hi) into the LDS bit array `dst` at bit offset `at`
+__device__ __forceinline__ void lds_or_bits(uint32_t *dst, uint32_t at, unsigned long long lo, unsigned long long hi, uint32_t n_bits) {
+    if (n_bits == 0) return;
+    const uint32_t w0 = at >> 5, sh = at & 31u;
+    const uint32_t x[5] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), 0u};
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const uint32_t v = sh ? ((x[i] << sh) | carry) : x[i];
+        carry = sh ? (x[i] >> (32u - sh)) : 0u;
+        if (v) atomicOr(&dst[w0 + i], v);                    // words past the lane's bits are all zero and skipped
+    }
+}
+
+__global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
+                                                const LaneState *__restrict__ lane_state, const L2 *__restrict__ chunk_l2_state,
+                                                uint32_t k, uint32_t n_chunks, uint32_t chunks_per_wg, uint32_t *__restrict__ codes,
+                                                uint32_t *__restrict__ restarts, uint32_t *__restrict__ n_bases,
+                                                DevRec *__restrict__ recs, uint64_t recs_cap, Carry *carry) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[WG * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint32_t slot_codes[SLOT_CODE_WORDS + 8];   // + slack: lds_or_bits touches up to 5 words
+    __shared__ __attribute__((aligned(16))) uint32_t slot_rst[SLOT_RST_WORDS + 8];
+    __shared__ uint32_t scan_sh[WG / 64];
+    __shared__ RecAcc racc;
+    const uint32_t km1 = k - 1;
+    for (uint32_t i = threadIdx.x; i < SLOT_CODE_WORDS + 8; i += WG) slot_codes[i] = 0;
+    for (uint32_t i = threadIdx.x; i < SLOT_RST_WORDS + 8; i += WG) slot_rst[i] = 0;
+    recacc_init(racc);
+    SeqWalker wk;
+    wk.setup(k, recs, recs_cap, &racc);
+    const uint32_t c_lo = blockIdx.x * chunks_per_wg, c_hi = min(c_lo + chunks_per_wg, n_chunks);
+    __syncthreads();
+    for (uint32_t c = c_lo; c < c_hi; c++) {
+        const uint64_t base = (uint64_t)c * CHUNK;
+        recacc_retarget(racc, chunk_l2_state[c].rec, recs, recs_cap);    // published by the barrier below
+        stage_chunk(fasta, base, n_bytes, lds);
+        __syncthreads();
+        const uint32_t nb = piece_len(base, n_bytes);
+        // exact parser state at this lane's first byte: chunk state . lane prefix (both from the structure pass)
+        const LaneState lst = lane_state[(uint64_t)c * WG + threadIdx.x];
+        const L2 st2 = l2_compose(chunk_l2_state[c], lane_state_l2(lst), km1);
+        wk.begin(lane_state_ls(lst), st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
+        PieceBases pb;
+        pb.clear();
+        for_each_byte(lds, nb, [&](uint32_t i, uint32_t ch, bool act) {
+            uint32_t code;
+            bool rst;
+            const bool take = wk.step(i, ch, act, code, rst);
+            pb.push(take, code, rst);
+        });
+        wk.flush_rec_wave();
+        // where the lane's bases go in the chunk's slot: exclusive prefix of the counts over the workgroup
+        uint32_t total;
+        const uint32_t at = wg_excl_scan_u32(pb.n, scan_sh, total);
+        lds_or_bits(slot_codes, 2u * at, pb.code_lo, pb.code_hi, 2u * pb.n);
+        lds_or_bits(slot_rst, at, pb.restart, 0ull, pb.n);
+        __syncthreads();
+        // slot -> HBM, 16 bytes per lane, only the words that hold bases; the LDS copy is cleared for the next chunk
+        const uint32_t code_q = (total + 63u) / 64u, rst_q = (total + 127u) / 128u;      // uint4 groups in use
+        uint4 *gc = reinterpret_cast<uint4 *>(codes + (uint64_t)c * SLOT_CODE_WORDS);
+        uint4 *gr = reinterpret_cast<uint4 *>(restarts + (uint64_t)c * SLOT_RST_WORDS);
+        if (threadIdx.x < code_q) {
+            gc[threadIdx.x] = reinterpret_cast<uint4 *>(slot_codes)[threadIdx.x];
+            reinterpret_cast<uint4 *>(slot_codes)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+        }
+        if (threadIdx.x < rst_q) {
+            gr[threadIdx.x] = reinterpret_cast<uint4 *>(slot_rst)[threadIdx.x];
+            reinterpret_cast<uint4 *>(slot_rst)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+        }
+        if (threadIdx.x == 0) {
+            n_bases[c] = total;
+            slot_codes[SLOT_CODE_WORDS] = 0; slot_rst[SLOT_RST_WORDS] = 0;               // the slack words a full slot may have touched
+        }
+        __syncthreads();                                   // pieces consumed, slot cleared; LDS may be restaged
+    }
+    wk.finish();
+    recacc_finish(racc, recs, recs_cap, carry);
+}
+
+void launch_squeeze(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, uint32_t k,
+                    uint32_t n_chunks, uint32_t n_wg, uint32_t chunks_per_wg, uint32_t *codes, uint32_t *restarts, uint32_t *n_bases,
+                    DevRec *recs, uint64_t recs_cap, Carry *carry, hipStream_t s) {
+    hipLaunchKernelGGL(k_squeeze, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, k, n_chunks, chunks_per_wg, codes,
+                       restarts, n_bases, recs, recs_cap, carry);
+}
+
+}  // namespace pk

@@ -1,16 +1,13 @@
-// kmer_part.hip -- table update, version 2 ("partitioned"): no HBM atomics on the count table.
+// kmer_part.hip -- table update ("partitioned"): no HBM atomics on the count table.
 //
-// Version 1 (kmer_count.hip, k_count) issues one global atomic per k-mer into a 4^k-entry table; on
-// MI355X scattered device-scope atomics execute at the memory side and top out near 4.6 G/s
-// (measured, profiles/round01_v1_direct_*), i.e. ~4.7 Gbp/s however good the parser is.  Here the
-// canonical k-mers are instead routed to the workgroup that owns their slice of the address space:
+// One global atomic per k-mer into a 4^k-entry table tops out near 7.6 G/s on MI355X (scattered device-scope
+// atomics execute at the memory side; measured in round 1), i.e. ~7.5 Gbp/s however good the parser is.
+// Here the canonical k-mers are instead routed to the workgroup that owns their slice of the address space:
 //
-//   K0 k_walk_flat   FASTA -> canonical k-mers (same parser as v1), ballot-compacted per wave into
-//                    fixed per-(chunk,wave) regions of a flat record array; per-workgroup histogram
-//                    of the level-1 digit (top b1 address bits)
-//   K1 k_rows1_scan  column scan of those histograms -> exact output offset of every (workgroup, digit)
-//   K2 k_scatter1    LDS counting sort of each 16K-record tile by digit, coalesced run writes; for
-//                    k <= 15 it also tallies the size of every FINAL bucket (2^14 LDS counters per workgroup)
+//   kmer_pack.hip  k_squeeze     FASTA text -> packed valid bases (2-bit codes + restart bits), per-record tallies
+//   kmer_fuse.hip  k_walk_sort   packed bases -> canonical k-mers (in registers) -> LDS counting sort by the level-1
+//                                digit (top b1 address bits) -> coalesced run writes into provisioned buckets; for
+//                                k <= 15 it also tallies the size of every FINAL bucket (2^14 LDS counters per workgroup)
 //   K3 k_fine_sum / k_fine_scan  (k <= 15) final bucket starts + write cursors from those tallies
 //      k_count2 / k_rows2_scan   (k = 17)  per-workgroup histogram of the level-2 digit (next b2 bits)
 //                    inside each level-1 bucket, per-bucket column scan -> offsets + final bucket starts
@@ -19,466 +16,25 @@
 //   K6 k_bucket_count one workgroup per final bucket of 2^16 addresses: the slice of the u8 table
 //                    lives in LDS as 16-bit counters, ds_add per record, clamp, slice written to HBM
 //                    (read back first when an earlier feed already wrote it)
-//   K7 k_apply_side  the few hot k-mers the walk kept out of the record stream (below)
+//   K7 k_apply_side  the few hot k-mers the walk kept out of the record stream (part_common.h)
 //
-// Every pass is a stream: FASTA 0.8 GB + records 2.8+3.3+3.0+2.7+1.6+1.3 GB + table 1 GiB at
-// k=15 / 800 Mbp.  Bucket boundaries come from histograms + scans, so no pass needs a global atomic
-// per record.  With claimed runs the order of records inside a final bucket depends on timing; the
-// table -- a saturating sum per address -- does not.  Saturation is exact: min(255, .) is applied
+// Every pass is a stream.  Runs are claimed from cursors, so the order of records inside a bucket depends on
+// timing; the table -- a saturating sum per address -- does not.  Saturation is exact: min(255, .) is applied
 // only when a bucket's counters leave LDS (indexer.py:239,262), and K6 folds the slice already in
 // HBM back in, so several feeds accumulate exactly like the reference's flushes.
+//
+// `flags[0]` is raised by the level-1 sort when a provisioned bucket ran out of room (kmer_fuse.hip); every
+// kernel below then returns without touching anything and the host repeats the level with exact sizes.
 #include <cstddef>
 #include <cstdlib>
-#include "fasta_fsm.h"
-#include "kmer_walk.h"
-#include "pk_kernels.h"
+#include "part_common.h"
 
 namespace pk {
 
-constexpr int SUB = 4096;            // record slots per (chunk, wave) region of the flat array = PIECE * 64 lanes
-constexpr int SC_T = 1024;           // threads of the scatter / bucket-count workgroups
-constexpr int SC_PER = 16;           // records per thread per tile
-constexpr int TILE = SC_T * SC_PER;  // 16384 records per tile = one FASTA chunk's worth
-
-// ------------------------------------------------------------------ hot keys ---------------------
-// Tandem repeats (poly-A/T, (AT)n, (AAG)n ...) put tens of millions of identical canonical k-mers on a
-// handful of addresses; routed like everything else they would all land in ONE final bucket, i.e. on
-// one CU.  Each lane therefore remembers its last three distinct k-mers (periods 1-3 cover poly-N,
-// dinucleotide and trinucleotide repeats): a k-mer is emitted the first time it is seen, repeats while
-// it is remembered only bump a lane counter, and evicted counters are tallied in a per-workgroup LDS
-// hash table (addr -> count; lanes holding the same address are merged with ballot + readlane first),
-// which is appended to a global side list when the workgroup finishes (or the table half fills).
-// k_apply_side folds the side list into the finished u8 table with saturating CAS adds -- a few
-// thousand entries instead of 10^7..10^8 records.
-constexpr uint32_t HOT_SLOTS = 1024;     // per-workgroup LDS hash slots
-constexpr uint32_t HOT_PROBES = 16;
-constexpr uint32_t SIDE_CNT_BITS = 28;   // side entry = (addr << 28) | count
-
-struct HotTable {
-    unsigned long long key[HOT_SLOTS];   // addr + 1, 0 = empty
-    uint32_t val[HOT_SLOTS];
-    uint32_t used, n_flush;
-};
-
-__device__ __forceinline__ void side_append_one(unsigned long long *side, unsigned long long *side_n, uint64_t side_cap,
-                                                uint64_t addr, uint32_t cnt) {
-    unsigned long long i = atomicAdd(side_n, 1ull);
-    if (i < side_cap) side[i] = ((unsigned long long)addr << SIDE_CNT_BITS) | cnt;
-}
-
-__device__ __forceinline__ void hot_insert(HotTable &H, uint64_t addr, uint32_t cnt, unsigned long long *side,
-                                           unsigned long long *side_n, uint64_t side_cap) {
-    const unsigned long long key = addr + 1ull;
-    uint32_t h = (uint32_t)((addr * 0x9E3779B97F4A7C15ull) >> 40) & (HOT_SLOTS - 1u);
-#pragma unroll 1                                               // rare path, inlined sixteen times into the walk loop: keep it small
-    for (uint32_t t = 0; t < HOT_PROBES; t++) {
-        unsigned long long old = atomicCAS(&H.key[h], 0ull, key);
-        if (old == 0ull || old == key) {
-            if (old == 0ull) atomicAdd(&H.used, 1u);
-            atomicAdd(&H.val[h], cnt);
-            return;
-        }
-        h = (h + 1u) & (HOT_SLOTS - 1u);
-    }
-    side_append_one(side, side_n, side_cap, addr, cnt);          // table crowded: straight to the side list
-}
-
-// Whole wave (uniform call): every lane with n > 0 contributes (addr, n); lanes holding the same addr
-// are summed with ballot + readlane and inserted once.  Deliberately not inlined: it runs a few times
-// per piece at most and would otherwise be replicated through the unrolled walk loop.
-__device__ __noinline__ void hot_insert_wave(HotTable *H, unsigned long long addr, uint32_t n, unsigned long long *side,
-                                             unsigned long long *side_n, uint64_t side_cap) {
-    const int lane = threadIdx.x & 63;
-    unsigned long long pending = __ballot(n != 0u);
-    while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const unsigned long long a = __shfl(addr, leader, 64);
-        const bool mine = n != 0u && addr == a;
-        const unsigned long long same = __ballot(mine);
-        uint32_t tot = mine ? n : 0u;
-        for (int d = 32; d; d >>= 1) tot += __shfl_xor(tot, d, 64);
-        if (lane == leader) hot_insert(*H, a, tot, side, side_n, side_cap);
-        pending &= ~same;
-    }
-}
-
-// all threads of the workgroup; appends every occupied slot to the side list and clears the table
-__device__ __forceinline__ void hot_flush(HotTable &H, unsigned long long *side, unsigned long long *side_n, uint64_t side_cap) {
-    __syncthreads();
-    if (threadIdx.x == 0) H.n_flush = 0;
-    __syncthreads();
-    uint32_t mine = 0;
-    for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += blockDim.x) mine += H.key[i] != 0ull;
-    uint32_t at = mine ? atomicAdd(&H.n_flush, mine) : 0u;
-    __syncthreads();
-    __shared__ unsigned long long base64;
-    if (threadIdx.x == 0) base64 = H.n_flush ? atomicAdd(side_n, (unsigned long long)H.n_flush) : 0ull;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += blockDim.x) {
-        if (H.key[i] != 0ull) {
-            unsigned long long dst = base64 + at++;
-            if (dst < side_cap) side[dst] = ((H.key[i] - 1ull) << SIDE_CNT_BITS) | H.val[i];
-            H.key[i] = 0ull; H.val[i] = 0u;
-        }
-    }
-    if (threadIdx.x == 0) H.used = 0;
-    __syncthreads();
-}
-
-// ------------------------------------------------------------------ K0: walk -> flat records ----
-template <typename KT, typename REC0, bool DBG>
-__global__ __launch_bounds__(WG) void k_walk_flat(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
-                                                  const LaneState *__restrict__ lane_state, const L2 *__restrict__ chunk_l2_state,
-                                                  PartPlan pl, REC0 *__restrict__ flat, uint32_t *__restrict__ cnt,
-                                                  uint32_t *__restrict__ hist1_rows, DevRec *__restrict__ recs, uint64_t recs_cap,
-                                                  Carry *carry, unsigned long long *__restrict__ side,
-                                                  unsigned long long *__restrict__ side_n, uint64_t side_cap) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[WG * LDS_STRIDE];
-    __shared__ uint32_t hist1[512];
-    __shared__ HotTable hot;
-    for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += WG) { hot.key[i] = 0ull; hot.val[i] = 0u; }
-    if (threadIdx.x == 0) hot.used = 0;
-    const uint32_t k = pl.k, km1 = k - 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t d = threadIdx.x; d < pl.B1; d += WG) hist1[d] = 0;
-    const uint32_t shift1 = pl.addr_bits - pl.b1;
-    __shared__ RecAcc racc;
-    recacc_init(racc);
-    Walker<KT> wk;
-    wk.setup(k, recs, recs_cap, &racc);
-    const uint32_t c_lo = blockIdx.x * pl.G, c_hi = min(c_lo + pl.G, pl.n_chunks);
-    __syncthreads();
-    for (uint32_t c = c_lo; c < c_hi; c++) {
-        const uint64_t base = (uint64_t)c * CHUNK;
-        recacc_retarget(racc, chunk_l2_state[c].rec, recs, recs_cap);    // published by the barrier below
-        stage_chunk(fasta, base, n_bytes, lds);
-        __syncthreads();
-        const uint32_t nb = piece_len(base, n_bytes);
-        // exact parser state at this lane's first byte: chunk state . lane prefix (both from the structure pass)
-        const LaneState lst = lane_state[(uint64_t)c * WG + threadIdx.x];
-        const L2 st2 = l2_compose(chunk_l2_state[c], lane_state_l2(lst), km1);
-        const uint32_t ls_in = lane_state_ls(lst);
-        const bool walk_clean = __all(!lane_state_dirty(lst) && ls_in != LS_HEADER && st2.p_tail == 0);
-        wk.begin(ls_in, st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
-
-        // wave-uniform base of this wave's record region (kept in scalar registers: stores use saddr + lane offset)
-        const uint64_t region_i = ((uint64_t)c * (WG / 64) + wave) * SUB;
-        REC0 *region = flat + (((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(region_i >> 32)) << 32) |
-                               __builtin_amdgcn_readfirstlane((uint32_t)region_i));
-        uint32_t wcount = 0;                               // wave-uniform
-        // wave-uniform call: ballot-compact this step's records into the wave's region (coalesced store)
-        const uint32_t dbg = DBG ? pl.dbg : 0u;          // ablation bits exist only in the diagnostic instantiation
-        auto wave_emit = [&](bool e, KT a) {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(e);   // takes the lane mask as it is (__ballot goes through an int)
-            if (e) {
-                // inside the branch the execution mask IS the ballot: rank among the emitting lanes from it
-                const unsigned long long live = __builtin_amdgcn_read_exec();
-                const uint32_t p = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-                if (!(dbg & 4u)) *reinterpret_cast<REC0 *>(reinterpret_cast<char *>(region) + p * (uint32_t)sizeof(REC0)) = (REC0)a;   // 32-bit lane offset
-                const uint32_t digit = sizeof(KT) == 4 ? (uint32_t)a >> (shift1 & 31u) : (uint32_t)((uint64_t)a >> shift1);
-                if (!(dbg & 2u)) atomicAdd(&hist1[digit], 1u);
-            }
-            wcount += __popcll(m);
-        };
-        // The lane remembers its last three distinct k-mers.  A k-mer is emitted the first time it is seen;
-        // seeing it again while remembered (tandem repeats of period 1-3: the contended buckets) only
-        // bumps a counter, which goes to the workgroup's LDS table when the entry is evicted or the piece
-        // ends.  Either route counts each k-mer exactly once.  a1, a2, a3 are pairwise distinct (an entry
-        // is only ever inserted on a miss; the initial ~0 is no k-mer), so at most one compare hits.
-        KT a1 = ~(KT)0, a2 = ~(KT)0, a3 = ~(KT)0;
-        uint32_t nn = 0;
-        auto route = [&](bool has, KT canon) {
-            const bool e1 = canon == a1, e2 = canon == a2, e3 = canon == a3;
-            const bool h1 = has & e1, h2 = has & e2, h3 = has & e3;
-            const bool miss = has & !e1 & !e2 & !e3;
-            // the three counters live in one register (7 bits each are plenty: a piece has 64 steps, and
-            // the entries are drained after every piece): n1 | n2 << 8 | n3 << 16
-            nn += h1 ? 1u : (h2 ? 0x100u : (h3 ? 0x10000u : 0u));
-            const uint32_t ev_n = miss ? (nn >> 16) : 0u;
-            const KT ev_a = a3;
-            a3 = miss ? a2 : a3;
-            a2 = miss ? a1 : a2;
-            a1 = miss ? canon : a1;
-            nn = miss ? ((nn << 8) & 0xffff00u) : nn;
-            wave_emit((dbg & 1u) ? has : miss, canon);
-            if (ev_n != 0u) hot_insert(hot, (uint64_t)ev_a, ev_n, side, side_n, side_cap);   // rare: leaving a tandem run
-        };
-        if (dbg & 8u) {
-        } else if (walk_clean) {                             // the common case: plain sequence lines
-            wk.walk_clean(lds, nb, route);
-        } else {
-            for_each_byte(lds, nb, [&](uint32_t i, uint32_t ch, bool act) {
-                KT canon;
-                const bool has = wk.step(i, ch, act, canon);
-                route(has, canon);
-            });
-        }
-        hot_insert_wave(&hot, (unsigned long long)a1, nn & 0xffu, side, side_n, side_cap);     // drain the lane's entries
-        hot_insert_wave(&hot, (unsigned long long)a2, (nn >> 8) & 0xffu, side, side_n, side_cap);
-        hot_insert_wave(&hot, (unsigned long long)a3, nn >> 16, side, side_n, side_cap);
-        wk.flush_rec_wave();
-        if (lane == 0) cnt[c * (WG / 64) + wave] = wcount;
-        __syncthreads();                                   // pieces consumed; LDS may be restaged
-        if (hot.used >= HOT_SLOTS / 2) hot_flush(hot, side, side_n, side_cap);   // uniform: read after the barrier
-    }
-    hot_flush(hot, side, side_n, side_cap);
-    wk.finish();
-    recacc_finish(racc, recs, recs_cap, carry);
-    __syncthreads();
-    for (uint32_t d = threadIdx.x; d < pl.B1; d += WG) hist1_rows[(uint64_t)blockIdx.x * pl.B1 + d] = hist1[d];
-}
-
-// ------------------------------------------------------------------ K1: level-1 column scan -----
-// One 256-thread workgroup per digit d scans that column of the (workgroup x digit) histogram:
-// rowoff[w][d] = records of digit d written by rows < w.  The workgroup that finishes last (ticket
-// counter) turns the column totals into bucket_base[d] = start of bucket d and the level-2 work split:
-// bucket d gets ceil(n_d / R2) workgroups.
-__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *wsum, uint32_t &total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-    __syncthreads();                                       // wsum may still be read from an earlier call
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    uint32_t pre = 0;
-    for (int i = 0; i < w; i++) pre += wsum[i];
-    total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    return pre + inc - v;
-}
-
-__global__ __launch_bounds__(256) void k_rows1_scan(const uint32_t *__restrict__ hist_rows, uint32_t *__restrict__ rowoff, PartPlan pl,
-                                                    uint32_t *col_tot, unsigned int *ticket, uint32_t *__restrict__ bucket_base,
-                                                    uint32_t *__restrict__ wg2_start, uint32_t *__restrict__ final_start) {
-    __shared__ uint32_t wsum[4];
-    __shared__ uint32_t last;
-    const uint32_t B1 = pl.B1, d = blockIdx.x, n = pl.n_wg0;           // n <= 1024 rows: at most 4 per thread
-    const uint32_t r_lo = min(threadIdx.x * 4u, n), r_hi = min(r_lo + 4u, n);
-    uint32_t v[4], acc = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < 4; j++) {
-        v[j] = r_lo + j < r_hi ? hist_rows[(uint64_t)(r_lo + j) * B1 + d] : 0u;
-        acc += v[j];
-    }
-    uint32_t total;
-    uint32_t a = block_excl_scan_256(acc, wsum, total);
-#pragma unroll
-    for (uint32_t j = 0; j < 4; j++)
-        if (r_lo + j < r_hi) { rowoff[(uint64_t)(r_lo + j) * B1 + d] = a; a += v[j]; }
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&col_tot[d], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        last = atomicAdd(ticket, 1u) == B1 - 1u ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    // the last workgroup: exclusive scans of the column totals (bucket starts) and of the per-bucket
-    // level-2 workgroup counts, two digits per thread (B1 <= 512)
-    uint32_t t0 = 0, t1 = 0;
-    const uint32_t i0 = threadIdx.x * 2u, i1 = i0 + 1u;
-    if (i0 < B1) t0 = __hip_atomic_load(&col_tot[i0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (i1 < B1) t1 = __hip_atomic_load(&col_tot[i1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t g0 = (uint32_t)((t0 + pl.R2 - 1) / pl.R2), g1 = (uint32_t)((t1 + pl.R2 - 1) / pl.R2);
-    uint32_t sum_n, sum_g;
-    const uint32_t base = block_excl_scan_256(t0 + t1, wsum, sum_n);
-    const uint32_t wgs = block_excl_scan_256(g0 + g1, wsum, sum_g);
-    if (i0 < B1) { bucket_base[i0] = base; wg2_start[i0] = wgs; if (pl.b2 == 0) final_start[i0] = base; }
-    if (i1 < B1) { bucket_base[i1] = base + t0; wg2_start[i1] = wgs + g0; if (pl.b2 == 0) final_start[i1] = base + t0; }
-    if (threadIdx.x == 0) {
-        bucket_base[B1] = sum_n;
-        wg2_start[B1] = sum_g;
-        if (pl.b2 == 0) final_start[B1] = sum_n;
-    }
-}
-
-// ------------------------------------------------------------------ K2 / K5: scatter ------------
-// One tile = up to 16384 records: rank within digit by LDS atomic, exclusive scan of the digit
-// counts, records + digits parked in LDS in sorted order, then written as coalesced runs at
-// run[d] (this workgroup's running output offset for digit d).
-struct ScatterLds {
-    uint32_t hist[512], off[512], run[512], gbase[512];
-    uint32_t wsum[SC_T / 64];
-    uint32_t rec[TILE];
-    uint16_t dig[TILE];            // only when the digit does not fit beside the record (k = 17, level 1)
-};
-constexpr size_t SCATTER_LDS_NARROW = offsetof(ScatterLds, dig);   // 72 KiB: two workgroups per CU
-constexpr size_t SCATTER_LDS_WIDE = sizeof(ScatterLds);            // 104 KiB
-
-// WIDE = the digit is kept in its own LDS array; otherwise the record parked in LDS still carries its
-// digit (digit << shift | rest fits 32 bits) and is masked on the way out.
-// `claim` != nullptr: the tile's run for digit d starts where a global cursor says (atomicAdd of the
-// run length), instead of at this workgroup's precomputed running offset L.run[d].
-//
-// `settle()` is called once the tile is parked, right before its runs are stored.  The callers use it to
-// take delivery of the NEXT tile's prefetched records at that point.  On this ISA loads and stores share one
-// in-order counter (vmcnt): a wait placed after the stores -- where the compiler would put it, at the top
-// of the next tile -- also waits for the stores to be acknowledged by HBM, a full round trip of ~8 us per
-// tile with nothing else in flight.  Waiting here costs nothing (the loads were issued a whole sort ago)
-// and leaves the stores in flight through the next tile's ranking and parking.
-template <typename RIN, bool WIDE, class Settle>
-__device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PER], const bool (&ok)[SC_PER], uint32_t n_tile,
-                                             uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out,
-                                             Settle &&settle, uint32_t *claim = nullptr) {
-    uint32_t dr[SC_PER];                                   // digit (9 bits) | rank inside the tile << 9
-#pragma unroll
-    for (int j = 0; j < SC_PER; j++) {
-        dr[j] = 0;
-        if (ok[j]) {
-            const uint32_t dg = (uint32_t)((uint64_t)r[j] >> shift) & (B - 1u);
-            dr[j] = dg | (atomicAdd(&L.hist[dg], 1u) << 9);
-        }
-    }
-    __syncthreads();
-    // exclusive scan of hist[0..B) by the first B threads (B <= 512 <= SC_T)
-    uint32_t my_off = 0, claimed = 0;
-    {
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        uint32_t v = threadIdx.x < B ? L.hist[threadIdx.x] : 0u, inc = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-        if (lane == 63) L.wsum[w] = inc;
-        __syncthreads();
-        uint32_t pre = 0;
-        for (int i = 0; i < w; i++) pre += L.wsum[i];
-        my_off = pre + inc - v;
-        if (threadIdx.x < B) {
-            L.off[threadIdx.x] = my_off;
-            // a claimed run start is only needed when the runs are written: the atomic's round trip to HBM
-            // overlaps the parking of the records below
-            if (claim) claimed = v ? atomicAdd(&claim[threadIdx.x], v) : 0u;
-            else { L.gbase[threadIdx.x] = L.run[threadIdx.x] - my_off; L.run[threadIdx.x] += v; }
-            L.hist[threadIdx.x] = 0;                          // ready for the next tile
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < SC_PER; j++)
-        if (ok[j]) {
-            const uint32_t dg = dr[j] & 511u;
-            const uint32_t p = L.off[dg] + (dr[j] >> 9);
-            if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)dg; }
-            else L.rec[p] = (uint32_t)r[j];
-        }
-    if (claim && threadIdx.x < B) L.gbase[threadIdx.x] = claimed - my_off;   // sorted position p of digit d goes to p + gbase[d]
-    __syncthreads();
-    settle();
-    if (out16) {
-        // 16-bit records: each thread takes pairs of neighbours in sorted order and writes them as one
-        // dword when they fall in the same run and the destination is even (the common case)
-        uint16_t *o16 = reinterpret_cast<uint16_t *>(out);
-#pragma unroll
-        for (int j = 0; j < SC_PER / 2; j++) {
-            const uint32_t p = 2u * (threadIdx.x + j * SC_T);
-            if (p < n_tile) {
-                const uint32_t r0 = L.rec[p], r1 = p + 1 < n_tile ? L.rec[p + 1] : 0u;
-                const uint32_t d0 = WIDE ? L.dig[p] : (r0 >> shift) & (B - 1u);
-                const uint32_t d1 = p + 1 < n_tile ? (WIDE ? (uint32_t)L.dig[p + 1] : (r1 >> shift) & (B - 1u)) : ~0u;
-                const uint32_t dst0 = p + L.gbase[d0];
-                if (d0 == d1 && (dst0 & 1u) == 0u) {
-                    *reinterpret_cast<uint32_t *>(o16 + dst0) = (r0 & low_mask) | ((r1 & low_mask) << 16);
-                } else {
-                    o16[dst0] = (uint16_t)(r0 & low_mask);
-                    if (p + 1 < n_tile) o16[p + 1 + L.gbase[d1]] = (uint16_t)(r1 & low_mask);
-                }
-            }
-        }
-    } else {
-        // 32-bit records: neighbours in sorted order leave as one 8-byte store when they share a run
-        uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
-#pragma unroll
-        for (int j = 0; j < SC_PER / 2; j++) {
-            const uint32_t p = 2u * (threadIdx.x + j * SC_T);
-            if (p < n_tile) {
-                const uint32_t r0 = L.rec[p], r1 = p + 1 < n_tile ? L.rec[p + 1] : 0u;
-                const uint32_t d0 = WIDE ? L.dig[p] : (r0 >> shift) & (B - 1u);
-                const uint32_t d1 = p + 1 < n_tile ? (WIDE ? (uint32_t)L.dig[p + 1] : (r1 >> shift) & (B - 1u)) : ~0u;
-                const uint32_t dst0 = p + L.gbase[d0];
-                if (d0 == d1 && (dst0 & 1u) == 0u) {
-                    *reinterpret_cast<uint2 *>(o32 + dst0) = make_uint2(r0 & low_mask, r1 & low_mask);
-                } else {
-                    o32[dst0] = r0 & low_mask;
-                    if (p + 1 < n_tile) o32[p + 1 + L.gbase[d1]] = r1 & low_mask;
-                }
-            }
-        }
-    }
-    __syncthreads();
-}
-
-// level 1: source = the flat (chunk, wave) regions written by k_walk_flat; workgroup w owns the same
-// chunk range as walk workgroup w, so its row of offsets applies.
-// FINE: also tally, per workgroup, how many records go to every FINAL bucket (top b1+b2 address bits, at
-// most 2^14 of them: 64 KiB of LDS counters behind the tile) and write that row out; summed over the
-// workgroups it gives the final bucket sizes, so level 2 needs no counting pass over the records.
-template <typename REC0, bool FINE>
-__global__ __launch_bounds__(SC_T) void k_scatter1(const REC0 *__restrict__ flat, const uint32_t *__restrict__ cnt,
-                                                   const uint32_t *__restrict__ rowoff, const uint32_t *__restrict__ bucket_base,
-                                                   PartPlan pl, void *__restrict__ out, uint32_t *__restrict__ fine_rows) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    ScatterLds &L = *reinterpret_cast<ScatterLds *>(smem);
-    uint32_t *fine = reinterpret_cast<uint32_t *>(smem + SCATTER_LDS_NARROW);      // [B1 * B2], FINE only
-    const uint32_t n_fine = pl.B1 * pl.B2;
-    if (FINE) for (uint32_t i = threadIdx.x; i < n_fine; i += SC_T) fine[i] = 0u;
-    const uint32_t B = pl.B1, shift = pl.addr_bits - pl.b1;
-    const uint32_t low_mask = shift >= 32 ? 0xffffffffu : ((1u << shift) - 1u);
-    const bool out16 = pl.b2 == 0;
-    if (threadIdx.x < 512) { L.hist[threadIdx.x] = 0; L.run[threadIdx.x] = 0; }
-    __syncthreads();
-    if (threadIdx.x < B) L.run[threadIdx.x] = bucket_base[threadIdx.x] + rowoff[(uint64_t)blockIdx.x * B + threadIdx.x];
-    __syncthreads();
-    const uint32_t c_lo = blockIdx.x * pl.G, c_hi = min(c_lo + pl.G, pl.n_chunks);
-    // one tile = the four wave regions of one chunk (SUB slots each, n[s] of them filled).  Thread t takes
-    // slots 4t .. 4t+3 of every region with one 16-byte (32-byte for 64-bit records) load; slots past
-    // n[s] are allocated but hold no record -- they are read anyway and masked, which keeps the loads
-    // branch-free.
-    static_assert(SUB == 4 * SC_T && SC_PER == 16, "tile layout");
-    typedef uint32_t Counts __attribute__((ext_vector_type(4)));         // records in the chunk's four regions
-    auto meta = [&](uint32_t c) { return *reinterpret_cast<const Counts *>(cnt + (uint64_t)c * 4); };
-    typedef REC0 Quad __attribute__((ext_vector_type(4)));               // one load, one register tuple, one asm operand
-    auto fetch = [&](uint32_t c, Quad (&q)[4]) {
-        const Quad *src = reinterpret_cast<const Quad *>(flat + (uint64_t)c * 4 * SUB) + threadIdx.x;
-#pragma unroll
-        for (int sreg = 0; sreg < 4; sreg++) q[sreg] = src[sreg * (SUB / 4)];
-    };
-    // The next chunk's loads are issued before the current tile is sorted, so they fly during its barriers;
-    // settle() (see scatter_tile) takes delivery of them before the current tile's stores are issued.  The
-    // empty asm makes the registers "defined here" for the compiler, so it adds no wait of its own later.
-    Quad nxt[4] = {};
-    Counts nxt_n = {0u, 0u, 0u, 0u};
-    auto settle = [&]() {
-        __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0); lgkmcnt / expcnt untouched
-        asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt_n));
-    };
-    if (c_lo < c_hi) { nxt_n = meta(c_lo); fetch(c_lo, nxt); }
-    settle();
-    for (uint32_t c = c_lo; c < c_hi; c++) {
-        REC0 r[SC_PER];
-        const uint32_t tile_n[4] = {nxt_n.x, nxt_n.y, nxt_n.z, nxt_n.w};
-        const uint32_t tile_total = tile_n[0] + tile_n[1] + tile_n[2] + tile_n[3];
-#pragma unroll
-        for (int j = 0; j < SC_PER; j++) r[j] = nxt[j >> 2][j & 3];
-        if (c + 1 < c_hi) { nxt_n = meta(c + 1); fetch(c + 1, nxt); }
-        if (tile_total == 0) { settle(); continue; }
-        bool ok[SC_PER];
-#pragma unroll
-        for (int j = 0; j < SC_PER; j++) ok[j] = threadIdx.x * 4u + (j & 3) < tile_n[j >> 2];
-        if (FINE) {
-#pragma unroll
-            for (int j = 0; j < SC_PER; j++)
-                if (ok[j]) atomicAdd(&fine[(uint32_t)((uint64_t)r[j] >> pl.fb_bits)], 1u);
-        }
-        scatter_tile<REC0, sizeof(REC0) == 8>(L, r, ok, tile_total, shift, B, low_mask, out16, out, settle);
-    }
-    if (FINE) {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n_fine; i += SC_T) fine_rows[(uint64_t)blockIdx.x * n_fine + i] = fine[i];
-    }
-}
-
 // column sums of the per-workgroup final-bucket tallies: grid (n_fine / 256, row groups)
 __global__ __launch_bounds__(256) void k_fine_sum(const uint32_t *__restrict__ fine_rows, uint32_t n_rows, uint32_t n_fine,
-                                                  uint32_t *__restrict__ fine_tot) {
+                                                  uint32_t *__restrict__ fine_tot, const uint32_t *__restrict__ flags) {
+    if (flags[0]) return;
     const uint32_t col = blockIdx.x * 256u + threadIdx.x;
     if (col >= n_fine) return;
     const uint32_t per = (n_rows + gridDim.y - 1) / gridDim.y;
@@ -490,8 +46,10 @@ __global__ __launch_bounds__(256) void k_fine_sum(const uint32_t *__restrict__ f
 
 // exclusive scan of the final bucket sizes -> final_start[0 .. n_fine] and the write cursors level 2 claims from
 __global__ __launch_bounds__(1024) void k_fine_scan(const uint32_t *__restrict__ fine_tot, uint32_t n_fine,
-                                                    uint32_t *__restrict__ final_start, uint32_t *__restrict__ cursor) {
+                                                    uint32_t *__restrict__ final_start, uint32_t *__restrict__ cursor,
+                                                    const uint32_t *__restrict__ flags) {
     __shared__ uint32_t wsum[16];
+    if (flags[0]) return;
     const uint32_t per = (n_fine + 1023u) / 1024u;                       // <= 16
     const uint32_t lo = min(threadIdx.x * per, n_fine), hi = min(lo + per, n_fine);
     uint32_t acc = 0;
@@ -510,7 +68,8 @@ __global__ __launch_bounds__(1024) void k_fine_scan(const uint32_t *__restrict__
 
 // level-2 work split: bucket b is covered by workgroups wg2_start[b] .. wg2_start[b+1]-1, R2 records each
 __device__ __forceinline__ bool wg2_range(const uint32_t *__restrict__ wg2_start, const uint32_t *__restrict__ bucket_base,
-                                          const PartPlan &pl, uint32_t &b, uint32_t &lo, uint32_t &hi) {
+                                          const uint32_t *__restrict__ bucket_end, const PartPlan &pl, uint32_t &b, uint32_t &lo,
+                                          uint32_t &hi) {
     const uint32_t w = blockIdx.x;
     if (w >= wg2_start[pl.B1]) return false;
     uint32_t a = 0, z = pl.B1;                              // last b with wg2_start[b] <= w
@@ -518,18 +77,20 @@ __device__ __forceinline__ bool wg2_range(const uint32_t *__restrict__ wg2_start
     b = a;
     uint64_t s = (uint64_t)bucket_base[b] + (uint64_t)(w - wg2_start[b]) * pl.R2;
     uint64_t e = s + pl.R2;
-    if (e > bucket_base[b + 1]) e = bucket_base[b + 1];
+    if (e > bucket_end[b]) e = bucket_end[b];              // the bucket's records; the rest of its room stays unused
     lo = (uint32_t)s; hi = (uint32_t)e;
     return true;
 }
 
 __global__ __launch_bounds__(WG) void k_count2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ wg2_start,
-                                               const uint32_t *__restrict__ bucket_base, PartPlan pl, uint32_t *__restrict__ hist_rows) {
+                                               const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ bucket_end, PartPlan pl,
+                                               uint32_t *__restrict__ hist_rows, const uint32_t *__restrict__ flags) {
     __shared__ uint32_t h[512];
+    if (flags[0]) return;
     for (uint32_t d = threadIdx.x; d < pl.B2; d += WG) h[d] = 0;
     __syncthreads();
     uint32_t b, lo, hi;
-    const bool live = wg2_range(wg2_start, bucket_base, pl, b, lo, hi);
+    const bool live = wg2_range(wg2_start, bucket_base, bucket_end, pl, b, lo, hi);
     const uint32_t shift = pl.fb_bits;
     if (live) {
         const uint32_t mask = pl.B2 - 1u;
@@ -546,10 +107,13 @@ __global__ __launch_bounds__(WG) void k_count2(const uint32_t *__restrict__ in, 
 }
 
 // K4: one workgroup per level-1 bucket, one thread per level-2 digit.
+// The level-2 output is compact again: final bucket starts count up from compact_base[b], the number of records in
+// the level-1 buckets before b.
 __global__ __launch_bounds__(512) void k_rows2_scan(const uint32_t *__restrict__ hist_rows, uint32_t *__restrict__ rowoff,
-                                                    const uint32_t *__restrict__ wg2_start, const uint32_t *__restrict__ bucket_base,
-                                                    PartPlan pl, uint32_t *__restrict__ final_start) {
+                                                    const uint32_t *__restrict__ wg2_start, const uint32_t *__restrict__ compact_base,
+                                                    PartPlan pl, uint32_t *__restrict__ final_start, const uint32_t *__restrict__ flags) {
     __shared__ uint32_t tot[512];
+    if (flags[0]) return;
     const uint32_t b = blockIdx.x, d = threadIdx.x;
     uint32_t acc = 0;
     if (d < pl.B2)
@@ -561,7 +125,7 @@ __global__ __launch_bounds__(512) void k_rows2_scan(const uint32_t *__restrict__
     tot[d] = d < pl.B2 ? acc : 0;
     __syncthreads();
     if (d == 0) {
-        uint32_t a = bucket_base[b];
+        uint32_t a = compact_base[b];
         for (uint32_t i = 0; i < pl.B2; i++) { uint32_t n = tot[i]; final_start[(uint64_t)b * pl.B2 + i] = a; a += n; }
         if (b == pl.B1 - 1) final_start[(uint64_t)pl.B1 * pl.B2] = a;
     }
@@ -571,13 +135,14 @@ __global__ __launch_bounds__(512) void k_rows2_scan(const uint32_t *__restrict__
 // record lands inside its final bucket then depends on timing -- the bucket's contents as a multiset do not.
 template <bool CLAIM>
 __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ wg2_start,
-                                                   const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ rowoff,
-                                                   const uint32_t *__restrict__ final_start, PartPlan pl, void *__restrict__ out,
-                                                   uint32_t *__restrict__ cursor) {
+                                                   const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ bucket_end,
+                                                   const uint32_t *__restrict__ rowoff, const uint32_t *__restrict__ final_start, PartPlan pl,
+                                                   void *__restrict__ out, uint32_t *__restrict__ cursor, const uint32_t *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     ScatterLds &L = *reinterpret_cast<ScatterLds *>(smem);
     uint32_t b, lo, hi;
-    if (!wg2_range(wg2_start, bucket_base, pl, b, lo, hi)) return;      // uniform per workgroup
+    if (flags[0]) return;
+    if (!wg2_range(wg2_start, bucket_base, bucket_end, pl, b, lo, hi)) return;      // uniform per workgroup
     const uint32_t B = pl.B2, shift = pl.fb_bits;
     const uint32_t low_mask = (1u << shift) - 1u;
     if (threadIdx.x < 512) { L.hist[threadIdx.x] = 0; L.run[threadIdx.x] = 0; }
@@ -669,11 +234,13 @@ struct SliceTally {
 // with the part, so several workgroups fit on a CU and hide each other's phases.
 template <int T>
 __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
-                                                  uint32_t fb_bits, uint32_t split_bits, uint8_t *__restrict__ table8, uint32_t fresh,
-                                                  int *__restrict__ bucket_hist, uint8_t *smem, int *dh) {
+                                                  const uint32_t *__restrict__ final_end, uint32_t fb_bits, uint32_t split_bits,
+                                                  uint8_t *__restrict__ table8, uint32_t fresh, int *__restrict__ bucket_hist, uint8_t *smem,
+                                                  int *dh) {
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);                  // 2^fb_bits / 2 dwords
     const uint32_t fb = blockIdx.x >> split_bits, part = blockIdx.x & ((1u << split_bits) - 1u);
-    const uint32_t start = final_start[fb], end = final_start[fb + 1];
+    // final buckets lie back to back (end = the next one's start) unless they ARE the provisioned level-1 buckets
+    const uint32_t start = final_start[fb], end = final_end ? final_end[fb] : final_start[fb + 1];
     const uint32_t part_bits = fb_bits - split_bits;
     const uint32_t n_addr = 1u << part_bits;                             // addresses this workgroup owns
     uint8_t *slice = table8 + ((uint64_t)fb << fb_bits) + (uint64_t)part * n_addr;
@@ -841,23 +408,29 @@ __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ r
 // meant to run two to a CU, which takes at most 64 vector registers.
 template <int T>
 __global__ __launch_bounds__(T) void k_bucket_count(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
-                                                    uint32_t fb_bits, uint32_t split_bits, uint8_t *__restrict__ table8, uint32_t fresh,
-                                                    int *__restrict__ bucket_hist) {
+                                                    const uint32_t *__restrict__ final_end, uint32_t fb_bits, uint32_t split_bits,
+                                                    uint8_t *__restrict__ table8, uint32_t fresh, int *__restrict__ bucket_hist,
+                                                    const uint32_t *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int dh[256];
-    bucket_count_body<T>(recs, final_start, fb_bits, split_bits, table8, fresh, bucket_hist, smem, dh);
+    if (flags[0]) return;
+    bucket_count_body<T>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, bucket_hist, smem, dh);
 }
 template <int T>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_bucket_count_half(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start, uint32_t fb_bits, uint32_t split_bits,
-                         uint8_t *__restrict__ table8, uint32_t fresh, int *__restrict__ bucket_hist) {
+void k_bucket_count_half(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start, const uint32_t *__restrict__ final_end,
+                         uint32_t fb_bits, uint32_t split_bits, uint8_t *__restrict__ table8, uint32_t fresh, int *__restrict__ bucket_hist,
+                         const uint32_t *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int dh[256];
-    bucket_count_body<T>(recs, final_start, fb_bits, split_bits, table8, fresh, bucket_hist, smem, dh);
+    if (flags[0]) return;
+    bucket_count_body<T>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, bucket_hist, smem, dh);
 }
 
 // sums the per-bucket histogram rows into the running 256-bin histogram (signed deltas: two's complement adds)
-__global__ __launch_bounds__(256) void k_hist_reduce(const int *__restrict__ bucket_hist, uint32_t n_rows, unsigned long long *__restrict__ hist) {
+__global__ __launch_bounds__(256) void k_hist_reduce(const int *__restrict__ bucket_hist, uint32_t n_rows, unsigned long long *__restrict__ hist,
+                                                     const uint32_t *__restrict__ flags) {
+    if (flags[0]) return;
     long long acc = 0;
     uint32_t r = blockIdx.x;
     for (; r + 7 * gridDim.x < n_rows; r += 8 * gridDim.x) {             // eight independent row loads in flight
@@ -896,8 +469,10 @@ __device__ __forceinline__ void table_sat_add(uint8_t *table8, uint64_t addr, ui
 }
 
 __global__ __launch_bounds__(WG) void k_apply_side(const unsigned long long *__restrict__ side, const unsigned long long *__restrict__ side_n,
-                                                   uint64_t side_cap, uint8_t *__restrict__ table8, unsigned long long *__restrict__ hist) {
+                                                   uint64_t side_cap, uint8_t *__restrict__ table8, unsigned long long *__restrict__ hist,
+                                                   const uint32_t *__restrict__ flags) {
     __shared__ unsigned long long key[AS_SLOTS];
+    if (flags[0]) return;
     __shared__ uint32_t val[AS_SLOTS];
     __shared__ int dh[256];                                              // this workgroup's change to the value histogram
     unsigned long long n = *side_n;
@@ -952,32 +527,38 @@ PartPlan make_part_plan(uint32_t k, uint64_t n_bytes) {
     uint64_t r2 = (n_bytes + 1023) / 1024;
     pl.R2 = r2 < (uint64_t)TILE ? (uint64_t)TILE : ((r2 + TILE - 1) / TILE) * TILE;
     pl.n_wg2_max = (uint32_t)(n_bytes / pl.R2) + pl.B1 + 1;
-    const char *dbg = getenv("PK_DEBUG_WALK");
-    pl.dbg = dbg ? (uint32_t)atoi(dbg) : 0u;
+    // level-1 bucket sizes are estimated from every 16th slot; small inputs are counted exactly
+    pl.sample_stride = pl.n_chunks >= 1024u ? 16u : 1u;
+    // room for the level-1 buckets: the sampled estimate can reach the slot capacity (+1 per bucket from rounding
+    // up), each bucket gets 12.5 % + 4096 + alignment on top of it (k_provision)
+    const uint64_t est_max = (uint64_t)pl.n_chunks * TILE + pl.B1;
+    pl.capacity1 = est_max + est_max / 8 + (uint64_t)pl.B1 * 4100;
     return pl;
 }
 
 size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace *lay) {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t rec0 = pl.k > 15 ? 8 : 4;
     const uint64_t nfb = (uint64_t)pl.B1 * pl.B2;
     size_t o = 0;
-    lay->flat = o; o += up((size_t)pl.n_chunks * 4 * SUB * rec0);
-    lay->cnt = o; o += up((size_t)pl.n_chunks * 4 * 4);
-    lay->hist1 = o; o += up((size_t)pl.n_wg0 * pl.B1 * 4);
-    lay->rowoff1 = o; o += up((size_t)pl.n_wg0 * pl.B1 * 4);
+    lay->codes = o; o += up((size_t)pl.n_chunks * SLOT_CODE_WORDS * 4);
+    lay->restarts = o; o += up((size_t)pl.n_chunks * SLOT_RST_WORDS * 4);
+    lay->n_bases = o; o += up((size_t)pl.n_chunks * 4);
+    lay->sample_hist = o; o += up(512 * 4);
     lay->bucket_base = o; o += up((size_t)(pl.B1 + 1) * 4);
+    lay->bucket_end = o; o += up((size_t)(pl.B1 + 1) * 4);
+    lay->compact_base = o; o += up((size_t)(pl.B1 + 1) * 4);
+    lay->cursor1 = o; o += up((size_t)(pl.B1 + 1) * 4);
+    lay->cap_end = o; o += up((size_t)(pl.B1 + 1) * 4);
     lay->wg2_start = o; o += up((size_t)(pl.B1 + 1) * 4);
-    lay->col_tot = o; o += up((size_t)(pl.B1 + 1) * 4);
     lay->final_start = o; o += up((size_t)(nfb + 1) * 4);
-    lay->out1 = o; o += up((size_t)(n_bytes + 64) * (pl.b2 ? 4 : 2));
+    lay->out1 = o; o += up((size_t)(pl.capacity1 + TILE + 64) * (pl.b2 ? 4 : 2));      // buckets + the dump area
     lay->hist2 = o; o += up((size_t)pl.n_wg2_max * pl.B2 * 4);
     lay->rowoff2 = o; o += up((size_t)pl.n_wg2_max * pl.B2 * 4);
     lay->out2 = o; o += up(pl.b2 ? (size_t)(n_bytes + 64) * 2 : 256);
     lay->side_cap = n_bytes + 16;                          // every side entry stands for >= 1 k-mer
     lay->side = o; o += up((size_t)lay->side_cap * 8);
-    lay->side_n = o; o += 256;
-    const bool fine = pl.b2 && nfb <= 16384 && pl.k <= 15;             // level 2 without a counting pass (see k_scatter1)
+    lay->side_n = o; o += 256;                             // side-list length (u64), then the flags word
+    const bool fine = pl.b2 && nfb <= 16384 && pl.k <= 15;             // level 2 without a counting pass (see k_walk_sort)
     lay->fine_rows = o; o += fine ? up((size_t)pl.n_wg0 * nfb * 4) : 0;
     lay->fine_tot = o; o += fine ? up((size_t)nfb * 4) : 0;
     lay->cursor = o; o += fine ? up((size_t)nfb * 4) : 0;
@@ -985,81 +566,73 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
     return o;
 }
 
-int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, const PartPlan &pl,
-                       uint8_t *ws, const PartWorkspace &lay, uint8_t *table8, DevRec *recs, uint64_t recs_cap, Carry *carry,
-                       hipStream_t s, hipEvent_t ev_walk_end, hipEvent_t ev_part_end, bool fresh, unsigned long long *hist) {
-    uint32_t *cnt = (uint32_t *)(ws + lay.cnt), *hist1 = (uint32_t *)(ws + lay.hist1), *rowoff1 = (uint32_t *)(ws + lay.rowoff1);
-    uint32_t *bucket_base = (uint32_t *)(ws + lay.bucket_base), *wg2_start = (uint32_t *)(ws + lay.wg2_start);
-    uint32_t *final_start = (uint32_t *)(ws + lay.final_start), *hist2 = (uint32_t *)(ws + lay.hist2), *rowoff2 = (uint32_t *)(ws + lay.rowoff2);
-    void *flat = ws + lay.flat, *out1 = ws + lay.out1, *out2 = ws + lay.out2;
-    unsigned long long *side = (unsigned long long *)(ws + lay.side), *side_n = (unsigned long long *)(ws + lay.side_n);
-    const uint32_t nfb = pl.B1 * pl.B2;
-    const bool fine = pl.b2 && nfb <= 16384 && pl.k <= 15;
-    const size_t lds_fine = SCATTER_LDS_NARROW + (size_t)nfb * 4;
-    hipFuncSetAttribute((const void *)k_scatter1<uint32_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
-    hipFuncSetAttribute((const void *)k_scatter1<uint32_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SCATTER_LDS_NARROW + 65536));
-    hipFuncSetAttribute((const void *)k_scatter1<uint64_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_WIDE);
+void part_set_attributes() {
+    fuse_set_attributes();
     hipFuncSetAttribute((const void *)k_scatter2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_scatter2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_bucket_count<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute((const void *)k_bucket_count_half<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (hipMemsetAsync(side_n, 0, 16, s) != hipSuccess) return -2;   // side-list length + the column scan's ticket counter
-    if (pl.dbg && pl.k <= 15) {                              // diagnostic build of the walk (PK_DEBUG_WALK), timing only
-        hipLaunchKernelGGL((k_walk_flat<uint32_t, uint32_t, true>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, pl,
-                           (uint32_t *)flat, cnt, hist1, recs, recs_cap, carry, side, side_n, lay.side_cap);
-    } else if (pl.k <= 15) {
-        hipLaunchKernelGGL((k_walk_flat<uint32_t, uint32_t, false>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, pl,
-                           (uint32_t *)flat, cnt, hist1, recs, recs_cap, carry, side, side_n, lay.side_cap);
-    } else {
-        hipLaunchKernelGGL((k_walk_flat<uint64_t, uint64_t, false>), dim3(pl.n_wg0), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, pl,
-                           (uint64_t *)flat, cnt, hist1, recs, recs_cap, carry, side, side_n, lay.side_cap);
-    }
-    if (ev_walk_end) hipEventRecord(ev_walk_end, s);
-    if (pl.dbg && pl.k <= 15) {                              // ablation run: time the walk kernel only, results are garbage
-        if (ev_part_end) hipEventRecord(ev_part_end, s);
-        return hipGetLastError() == hipSuccess ? 0 : -2;
-    }
-    hipLaunchKernelGGL(k_rows1_scan, dim3(pl.B1), dim3(256), 0, s, hist1, rowoff1, pl, (uint32_t *)(ws + lay.col_tot),
-                       (unsigned int *)(side_n + 1), bucket_base, wg2_start, final_start);
+}
+
+// Everything behind the squeeze pass for one feed: bucket layout (sampled with `stride`; 1 = exact), the fused
+// k-mer assembly + level-1 sort, level 2, bucket count, side list.  Returns right after the launches; the
+// caller reads the flags word back to learn whether the layout held (flags[0] == 0).
+int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint32_t stride, uint8_t *ws, const PartWorkspace &lay, uint8_t *table8,
+                       hipStream_t s, hipEvent_t ev_sort_begin, hipEvent_t ev_sort_end, hipEvent_t ev_part_end, bool fresh,
+                       unsigned long long *hist) {
+    const uint32_t *codes = (const uint32_t *)(ws + lay.codes), *restarts = (const uint32_t *)(ws + lay.restarts);
+    const uint32_t *n_bases = (const uint32_t *)(ws + lay.n_bases);
+    uint32_t *sample_hist = (uint32_t *)(ws + lay.sample_hist), *bucket_base = (uint32_t *)(ws + lay.bucket_base);
+    uint32_t *bucket_end = (uint32_t *)(ws + lay.bucket_end), *compact_base = (uint32_t *)(ws + lay.compact_base);
+    uint32_t *cursor1 = (uint32_t *)(ws + lay.cursor1), *cap_end = (uint32_t *)(ws + lay.cap_end), *wg2_start = (uint32_t *)(ws + lay.wg2_start);
+    uint32_t *final_start = (uint32_t *)(ws + lay.final_start), *hist2 = (uint32_t *)(ws + lay.hist2), *rowoff2 = (uint32_t *)(ws + lay.rowoff2);
+    void *out1 = ws + lay.out1, *out2 = ws + lay.out2;
+    unsigned long long *side = (unsigned long long *)(ws + lay.side), *side_n = (unsigned long long *)(ws + lay.side_n);
+    uint32_t *flags = (uint32_t *)(side_n + 1);
+    const uint32_t nfb = pl.B1 * pl.B2;
+    const bool fine = pl.b2 && nfb <= 16384 && pl.k <= 15;
+    if (hipMemsetAsync(side_n, 0, 16, s) != hipSuccess) return -2;   // side-list length + flags
+    launch_provision(codes, restarts, n_bases, st2, pl, stride, (uint32_t)pl.capacity1, sample_hist, bucket_base, cursor1, cap_end, flags, s);
     uint32_t *fine_rows = (uint32_t *)(ws + lay.fine_rows), *fine_tot = (uint32_t *)(ws + lay.fine_tot), *cursor = (uint32_t *)(ws + lay.cursor);
+    if (ev_sort_begin) hipEventRecord(ev_sort_begin, s);
+    launch_walk_sort(codes, restarts, n_bases, st2, pl, out1, cursor1, cap_end, (uint32_t)pl.capacity1, flags, fine ? fine_rows : nullptr,
+                     bucket_base, bucket_end, compact_base, wg2_start, side, side_n, lay.side_cap, s);
+    if (ev_sort_end) hipEventRecord(ev_sort_end, s);
+    const uint16_t *final_recs = (const uint16_t *)out1;
+    const uint32_t *k6_start = bucket_base, *k6_end = bucket_end;        // b2 == 0: the level-1 buckets are the final ones
     if (fine) {
         if (hipMemsetAsync(fine_tot, 0, (size_t)nfb * 4, s) != hipSuccess) return -2;
-        hipLaunchKernelGGL((k_scatter1<uint32_t, true>), dim3(pl.n_wg0), dim3(SC_T), lds_fine, s, (const uint32_t *)flat, cnt, rowoff1,
-                           bucket_base, pl, out1, fine_rows);
-    } else if (pl.k <= 15)
-        hipLaunchKernelGGL((k_scatter1<uint32_t, false>), dim3(pl.n_wg0), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)flat, cnt, rowoff1,
-                           bucket_base, pl, out1, (uint32_t *)nullptr);
-    else
-        hipLaunchKernelGGL((k_scatter1<uint64_t, false>), dim3(pl.n_wg0), dim3(SC_T), SCATTER_LDS_WIDE, s, (const uint64_t *)flat, cnt, rowoff1,
-                           bucket_base, pl, out1, (uint32_t *)nullptr);
-    const uint16_t *final_recs = (const uint16_t *)out1;
-    if (fine) {
         const uint32_t row_groups = pl.n_wg0 < 16u ? 1u : 16u;
-        hipLaunchKernelGGL(k_fine_sum, dim3((nfb + 255u) / 256u, row_groups), dim3(256), 0, s, (const uint32_t *)fine_rows, pl.n_wg0, nfb, fine_tot);
-        hipLaunchKernelGGL(k_fine_scan, dim3(1), dim3(1024), 0, s, (const uint32_t *)fine_tot, nfb, final_start, cursor);
+        hipLaunchKernelGGL(k_fine_sum, dim3((nfb + 255u) / 256u, row_groups), dim3(256), 0, s, (const uint32_t *)fine_rows, pl.n_wg0, nfb, fine_tot,
+                           (const uint32_t *)flags);
+        hipLaunchKernelGGL(k_fine_scan, dim3(1), dim3(1024), 0, s, (const uint32_t *)fine_tot, nfb, final_start, cursor, (const uint32_t *)flags);
         hipLaunchKernelGGL(k_scatter2<true>, dim3(pl.n_wg2_max), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
-                           bucket_base, (const uint32_t *)nullptr, final_start, pl, out2, cursor);
-        final_recs = (const uint16_t *)out2;
+                           bucket_base, bucket_end, (const uint32_t *)nullptr, final_start, pl, out2, cursor, (const uint32_t *)flags);
+        final_recs = (const uint16_t *)out2; k6_start = final_start; k6_end = nullptr;
     } else if (pl.b2) {
-        hipLaunchKernelGGL(k_count2, dim3(pl.n_wg2_max), dim3(WG), 0, s, (const uint32_t *)out1, wg2_start, bucket_base, pl, hist2);
-        hipLaunchKernelGGL(k_rows2_scan, dim3(pl.B1), dim3(512), 0, s, hist2, rowoff2, wg2_start, bucket_base, pl, final_start);
+        hipLaunchKernelGGL(k_count2, dim3(pl.n_wg2_max), dim3(WG), 0, s, (const uint32_t *)out1, wg2_start, bucket_base, bucket_end, pl, hist2,
+                           (const uint32_t *)flags);
+        hipLaunchKernelGGL(k_rows2_scan, dim3(pl.B1), dim3(512), 0, s, hist2, rowoff2, wg2_start, compact_base, pl, final_start, (const uint32_t *)flags);
         hipLaunchKernelGGL(k_scatter2<false>, dim3(pl.n_wg2_max), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
-                           bucket_base, rowoff2, final_start, pl, out2, (uint32_t *)nullptr);
-        final_recs = (const uint16_t *)out2;
+                           bucket_base, bucket_end, rowoff2, final_start, pl, out2, (uint32_t *)nullptr, (const uint32_t *)flags);
+        final_recs = (const uint16_t *)out2; k6_start = final_start; k6_end = nullptr;
     }
     if (ev_part_end) hipEventRecord(ev_part_end, s);
     // sparse tables (few records per 2^16-address bucket, k=17): 2^split workgroups per bucket, see k_bucket_count
-    const uint32_t split = (pl.fb_bits == 16 && n / nfb < 8192) ? 1u : 0u;
+    const uint32_t split = (pl.fb_bits == 16 && n_bytes / nfb < 8192) ? 1u : 0u;
     const size_t part_addrs = (size_t)1 << (pl.fb_bits - split);
     const size_t lds6 = part_addrs * 2 < 64 ? 64 : part_addrs * 2;
     int *bucket_hist = (int *)(ws + lay.bucket_hist);
     const uint32_t n_rows6 = (uint32_t)(nfb << split);
     if (split)
-        hipLaunchKernelGGL(k_bucket_count_half<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, final_start, pl.fb_bits, split, table8, fresh ? 1u : 0u, bucket_hist);
+        hipLaunchKernelGGL(k_bucket_count_half<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, k6_start, k6_end, pl.fb_bits, split, table8,
+                           fresh ? 1u : 0u, bucket_hist, (const uint32_t *)flags);
     else
-        hipLaunchKernelGGL(k_bucket_count<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, final_start, pl.fb_bits, split, table8, fresh ? 1u : 0u, bucket_hist);
-    hipLaunchKernelGGL(k_hist_reduce, dim3(n_rows6 < 16u ? 1u : (n_rows6 / 16u > 2048u ? 2048u : n_rows6 / 16u)), dim3(256), 0, s, (const int *)bucket_hist, n_rows6, hist);
-    hipLaunchKernelGGL(k_apply_side, dim3(AS_WGS), dim3(WG), 0, s, side, side_n, lay.side_cap, table8, hist);
+        hipLaunchKernelGGL(k_bucket_count<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, k6_start, k6_end, pl.fb_bits, split, table8,
+                           fresh ? 1u : 0u, bucket_hist, (const uint32_t *)flags);
+    hipLaunchKernelGGL(k_hist_reduce, dim3(n_rows6 < 16u ? 1u : (n_rows6 / 16u > 2048u ? 2048u : n_rows6 / 16u)), dim3(256), 0, s, (const int *)bucket_hist,
+                       n_rows6, hist, (const uint32_t *)flags);
+    hipLaunchKernelGGL(k_apply_side, dim3(AS_WGS), dim3(WG), 0, s, side, side_n, lay.side_cap, table8, hist, (const uint32_t *)flags);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -1,11 +1,14 @@
-// kmer_walk.h -- the per-lane k-mer walker shared by both table-update versions.
+// kmer_walk.h -- the per-lane FASTA walker of the squeeze pass (kmer_pack.hip).
 //
-// One Walker holds the exact parser state at a lane's first byte (from the L1/L2 scans) and advances
-// it one byte per step(): line state, pending whitespace, the rolling forward / reverse-complement
-// values (indexer.py:146-150, as rolling updates) and the per-record tallies the reference keeps
-// (seq_len, valid windows, header text extent; indexer.py:75-95,349-351).  step() is written
-// branch-light -- predicates and selects for everything that happens on most bytes, real branches
-// only for the rare events (a header opens, interior whitespace resolves).
+// One SeqWalker holds the exact parser state at a lane's first byte (from the L1/L2 scans) and advances
+// it one byte per step(): line state, pending whitespace, the length of the current run of valid bases
+// and the per-record tallies the reference keeps (seq_len, valid windows, header text extent;
+// indexer.py:75-95,349-351).  It does not form k-mers: every valid base of a record is handed on as a
+// 2-bit code plus a "restart" flag (the run of valid bases begins anew at this base: a record opened, or
+// a character that maps to None came before it, indexer.py:36-41,144), and the k-mer values are
+// assembled from that packed stream by kmer_fuse.hip.  step() is written branch-light -- predicates and
+// selects for everything that happens on most bytes, real branches only for the rare events (a header
+// opens, interior whitespace resolves).
 #pragma once
 #include "fasta_fsm.h"
 #include "pk_kernels.h"
@@ -45,37 +48,44 @@ __device__ __forceinline__ void recacc_finish(RecAcc &A, DevRec *recs, uint64_t 
     }
 }
 
-template <typename KT>
-struct Walker {
+// What one lane hands to the packed stream for its 64-byte piece: the valid bases of live records in
+// text order, 2 bits each from bit 0 up (A 0, C 1, G 2, T 3 -- CONV, indexer.py:36-41), one restart
+// bit per base, and how many there are (<= 64).
+struct PieceBases {
+    unsigned long long code_lo, code_hi;   // bases 0-31, 32-63
+    unsigned long long restart;
+    uint32_t n;
+    __device__ __forceinline__ void clear() { code_lo = 0; code_hi = 0; restart = 0; n = 0; }
+    __device__ __forceinline__ void push(bool take, uint32_t code, bool rst) {
+        const uint32_t sh = (2u * n) & 63u;
+        const unsigned long long v = take ? ((unsigned long long)code << sh) : 0ull;
+        if (n < 32u) code_lo |= v; else code_hi |= v;
+        restart |= (take && rst) ? (1ull << (n & 63u)) : 0ull;
+        n += take ? 1u : 0u;
+    }
+};
+
+struct SeqWalker {
     // parser state
     uint32_t ls, run, rec;
     uint64_t pend;
-    KT fwd, rev;
     // tallies for the record being walked, and lane totals
     uint64_t seq_acc, kmer_acc, name_end, seq_tot, kmer_tot;
     // constants
-    uint32_t k, top;
-    KT mask;
+    uint32_t k;
     uint64_t pos0;
     DevRec *recs;
     uint64_t recs_cap;
     RecAcc *acc;                           // LDS
 
     __device__ __forceinline__ void setup(uint32_t k_, DevRec *recs_, uint64_t recs_cap_, RecAcc *acc_) {
-        k = k_; top = 2 * (k_ - 1);
-        mask = (KT)((k_ >= sizeof(KT) * 4) ? ~(KT)0 : (((KT)1 << (2 * k_)) - 1));
-        recs = recs_; recs_cap = recs_cap_; acc = acc_;
+        k = k_; recs = recs_; recs_cap = recs_cap_; acc = acc_;
         seq_tot = 0; kmer_tot = 0;
     }
 
     // start of a piece: ls_in / st2 are this lane's exact incoming states
     __device__ __forceinline__ void begin(uint32_t ls_in, const L2 &st2, uint64_t pos_first_byte) {
         ls = ls_in; pend = st2.p_tail; run = l2_len(st2); rec = st2.rec;
-        fwd = (KT)st2.bits; rev = 0;
-        for (uint32_t i = 0; i < run; i++) {           // reverse-complement value of the carried bases
-            uint32_t b = (st2.bits >> (2 * (run - 1 - i))) & 3u;
-            rev = (rev >> 2) | ((KT)(3u - b) << top);
-        }
         seq_acc = 0; kmer_acc = 0; name_end = 0;
         pos0 = pos_first_byte;
     }
@@ -110,60 +120,9 @@ struct Walker {
         if (seq_acc | kmer_acc | name_end) flush_rec();
     }
 
-    // A whole CLEAN piece (sequence characters and line terminators only, no pending blanks, not
-    // inside a header): the line/record machinery drops out and the loop is kept deliberately lean --
-    // 32-bit counters, integer flags, 16 bytes per iteration with constant shifts.  `sink(has, canon)`
-    // is called once per byte slot in wave-uniform control flow.
-    template <class Sink>
-    __device__ __forceinline__ void walk_clean(const uint8_t *lds, uint32_t nb, Sink &&sink) {
-        const uint4 *mine = reinterpret_cast<const uint4 *>(lds + threadIdx.x * LDS_STRIDE);
-        KT f = fwd, r = rev;
-        uint32_t n_seq = 0, n_kmer = 0;
-        // k is wanted as a vector operand in every step (select against a lane mask); pin one copy in a
-        // VGPR instead of letting the compiler re-create it from a spilled scalar each time
-        uint32_t kk;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(kk) : "s"(k));
-        const bool live = rec != 0;
-        int need = (int)(kk - run);                                      // bases still missing for a full window (<= 0: none)
-        // 16 bytes per ds_read_b128, fetched one iteration ahead; the 16 byte steps are unrolled with
-        // constant shifts (a rolled byte loop made the compiler issue one LDS read + full wait per byte).
-        // Bytes past the end of the stream were staged as 0 (stage_chunk) and behave like terminators here,
-        // so `nb` is not consulted.
-        (void)nb;
-        uint4 nxt = mine[0];
-#pragma unroll 1
-        for (uint32_t q = 0; q < (uint32_t)PIECE / 16u; q++) {
-            const uint4 cur = nxt;
-            if (q + 1u < (uint32_t)PIECE / 16u) nxt = mine[q + 1u];
-            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll 16
-            for (uint32_t j = 0; j < 16u; j++) {
-                const uint32_t c = (w[j >> 2] >> (8u * (j & 3u))) & 0xffu;
-                const bool seq = c > 13u;                                // clean piece: anything but \n / \r (/ 0 fill) is sequence text
-                // bits 1-2 of the letter pick the 2-bit code (A 0, C 1, T 3, G 2) and the letter it must be
-                const uint32_t idx2 = c & 6u;
-                const uint32_t code = (0xB4u >> idx2) & 3u;
-                const uint32_t expect = (0x47544341u >> (idx2 << 2)) & 0xffu;       // 'A' 'C' 'T' 'G'
-                const bool valid = (c & 0xDFu) == expect;                // either case; everything else is no base
-                const KT nf = (KT)(((f << 2) | (KT)code) & mask);        // indexer.py:149
-                const KT nr = (KT)((r >> 2) | ((KT)(3u ^ code) << top)); // indexer.py:150
-                f = valid ? nf : f;
-                r = valid ? nr : r;
-                const int fewer = need - (valid ? 1 : 0);                // may run below zero; a piece is far too short to wrap
-                need = (seq & !valid) ? (int)kk : fewer;                 // a non-base restarts the window, a terminator holds it
-                const bool has = valid & live & (need <= 0);
-                n_seq += seq ? 1u : 0u;
-                n_kmer += has ? 1u : 0u;
-                sink(has, (KT)(f < r ? f : r));
-            }
-        }
-        const uint32_t rn = need <= 0 ? kk : kk - (uint32_t)need;
-        fwd = f; rev = r; run = rn;
-        seq_acc += n_seq; kmer_acc += n_kmer;
-    }
-
-    // One byte.  Returns true when a valid window ends here; canon = min(fwd, rev) (indexer.py:341).
-    __device__ __forceinline__ bool step(uint32_t i, uint32_t c, bool act, KT &canon) {
+    // One byte.  Returns true when the byte is a valid base of a record (it joins the packed stream);
+    // `code` is its 2-bit value and `restart` tells whether the run of valid bases starts anew with it.
+    __device__ __forceinline__ bool step(uint32_t i, uint32_t c, bool act, uint32_t &code, bool &restart) {
         const bool term = is_term(c), ws = is_ws(c), gt = c == '>';
         const bool at_start = ls == LS_START, in_seq = ls == LS_SEQ;
         const bool hdr_start = act && at_start && !ws && gt;
@@ -182,17 +141,14 @@ struct Walker {
         pend = t ? 0ull : pend + ((act && ws && !term && in_seq) ? 1ull : 0ull);
         ls = t ? (uint32_t)LS_START : hdr_start ? (uint32_t)LS_HEADER : seqchar ? (uint32_t)LS_SEQ : ls;
         seq_acc += seqchar ? 1ull : 0ull;                          // indexer.py:77: valid or not
-        const uint32_t code = base_code(c);
-        const bool valid = seqchar && code < 4u;
-        const KT nf = (KT)(((fwd << 2) | (KT)(code & 3u)) & mask);                 // indexer.py:149
-        const KT nr = (KT)((rev >> 2) | ((KT)(3u - (code & 3u)) << top));          // indexer.py:150
-        fwd = valid ? nf : fwd;
-        rev = valid ? nr : rev;
+        const uint32_t cd = base_code(c);
+        const bool valid = seqchar && cd < 4u;
+        restart = run == 0u;
         run = valid ? (run < k ? run + 1 : run) : (seqchar ? 0u : run);
-        const bool has = valid && run == k && rec != 0;            // text before the first header is dropped
-        kmer_acc += has ? 1ull : 0ull;
-        canon = fwd < rev ? fwd : rev;
-        return has;
+        const bool live = rec != 0;                                // text before the first header is dropped (indexer.py:80-82)
+        kmer_acc += (valid && run == k && live) ? 1ull : 0ull;     // a window without None ends here (indexer.py:144)
+        code = cd & 3u;
+        return valid && live;
     }
 
     // after the last piece, all lanes: wave-reduce the lane totals into the workgroup accumulator

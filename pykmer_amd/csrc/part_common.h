@@ -1,0 +1,229 @@
+// part_common.h -- pieces shared by the partition kernels (kmer_fuse.hip: k-mer assembly + level-1 sort;
+// kmer_part.hip: level-2 sort, bucket count, side list): the per-workgroup hot-key table and the LDS
+// counting sort of one 16 K-record tile.
+#pragma once
+#include <cstddef>
+#include "fasta_fsm.h"
+#include "pk_kernels.h"
+
+namespace pk {
+
+constexpr int SC_T = 1024;           // threads of the scatter / bucket-count workgroups
+constexpr int SC_PER = 16;           // records per thread per tile
+constexpr int TILE = SC_T * SC_PER;  // 16384 records per tile = one FASTA chunk's worth (one base per byte at most)
+
+// ------------------------------------------------------------------ hot keys ---------------------
+// Tandem repeats (poly-A/T, (AT)n, (AAG)n ...) put tens of millions of identical canonical k-mers on a
+// handful of addresses; routed like everything else they would all land in ONE final bucket, i.e. on
+// one CU.  Each lane therefore remembers its last three distinct k-mers (periods 1-3 cover poly-N,
+// dinucleotide and trinucleotide repeats): a k-mer is emitted the first time it is seen, repeats while
+// it is remembered only bump a lane counter, and evicted counters are tallied in a per-workgroup LDS
+// hash table (addr -> count; lanes holding the same address are merged with ballot + readlane first),
+// which is appended to a global side list when the workgroup finishes (or the table half fills).
+// k_apply_side folds the side list into the finished u8 table with saturating CAS adds -- a few
+// thousand entries instead of 10^7..10^8 records.
+constexpr uint32_t HOT_SLOTS = 1024;     // per-workgroup LDS hash slots
+constexpr uint32_t HOT_PROBES = 16;
+constexpr uint32_t SIDE_CNT_BITS = 28;   // side entry = (addr << 28) | count
+
+struct HotTable {
+    unsigned long long key[HOT_SLOTS];   // addr + 1, 0 = empty
+    uint32_t val[HOT_SLOTS];
+    uint32_t used, n_flush;
+};
+
+__device__ __forceinline__ void side_append_one(unsigned long long *side, unsigned long long *side_n, uint64_t side_cap,
+                                                uint64_t addr, uint32_t cnt) {
+    unsigned long long i = atomicAdd(side_n, 1ull);
+    if (i < side_cap) side[i] = ((unsigned long long)addr << SIDE_CNT_BITS) | cnt;
+}
+
+__device__ __forceinline__ void hot_insert(HotTable &H, uint64_t addr, uint32_t cnt, unsigned long long *side,
+                                           unsigned long long *side_n, uint64_t side_cap) {
+    const unsigned long long key = addr + 1ull;
+    uint32_t h = (uint32_t)((addr * 0x9E3779B97F4A7C15ull) >> 40) & (HOT_SLOTS - 1u);
+#pragma unroll 1                                               // rare path, inlined sixteen times into the walk loop: keep it small
+    for (uint32_t t = 0; t < HOT_PROBES; t++) {
+        unsigned long long old = atomicCAS(&H.key[h], 0ull, key);
+        if (old == 0ull || old == key) {
+            if (old == 0ull) atomicAdd(&H.used, 1u);
+            atomicAdd(&H.val[h], cnt);
+            return;
+        }
+        h = (h + 1u) & (HOT_SLOTS - 1u);
+    }
+    side_append_one(side, side_n, side_cap, addr, cnt);          // table crowded: straight to the side list
+}
+
+// Whole wave (uniform call): every lane with n > 0 contributes (addr, n); lanes holding the same addr
+// are summed with ballot + readlane and inserted once.  Deliberately not inlined: it runs a few times
+// per piece at most and would otherwise be replicated through the unrolled walk loop.
+__device__ __noinline__ void hot_insert_wave(HotTable *H, unsigned long long addr, uint32_t n, unsigned long long *side,
+                                             unsigned long long *side_n, uint64_t side_cap) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long pending = __ballot(n != 0u);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const unsigned long long a = __shfl(addr, leader, 64);
+        const bool mine = n != 0u && addr == a;
+        const unsigned long long same = __ballot(mine);
+        uint32_t tot = mine ? n : 0u;
+        for (int d = 32; d; d >>= 1) tot += __shfl_xor(tot, d, 64);
+        if (lane == leader) hot_insert(*H, a, tot, side, side_n, side_cap);
+        pending &= ~same;
+    }
+}
+
+// all threads of the workgroup; appends every occupied slot to the side list and clears the table
+__device__ __forceinline__ void hot_flush(HotTable &H, unsigned long long *side, unsigned long long *side_n, uint64_t side_cap) {
+    __syncthreads();
+    if (threadIdx.x == 0) H.n_flush = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += blockDim.x) mine += H.key[i] != 0ull;
+    uint32_t at = mine ? atomicAdd(&H.n_flush, mine) : 0u;
+    __syncthreads();
+    __shared__ unsigned long long base64;
+    if (threadIdx.x == 0) base64 = H.n_flush ? atomicAdd(side_n, (unsigned long long)H.n_flush) : 0ull;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += blockDim.x) {
+        if (H.key[i] != 0ull) {
+            unsigned long long dst = base64 + at++;
+            if (dst < side_cap) side[dst] = ((H.key[i] - 1ull) << SIDE_CNT_BITS) | H.val[i];
+            H.key[i] = 0ull; H.val[i] = 0u;
+        }
+    }
+    if (threadIdx.x == 0) H.used = 0;
+    __syncthreads();
+}
+
+
+// ------------------------------------------------------------------ K2 / K5: scatter ------------
+// One tile = up to 16384 records: rank within digit by LDS atomic, exclusive scan of the digit
+// counts, records + digits parked in LDS in sorted order, then written as coalesced runs at
+// run[d] (this workgroup's running output offset for digit d).
+struct ScatterLds {
+    uint32_t hist[512], off[512], run[512], gbase[512];
+    uint32_t wsum[SC_T / 64];
+    uint32_t total, pad_[3];       // records of the tile being sorted
+    uint32_t rec[TILE];
+    uint16_t dig[TILE];            // only when the digit does not fit beside the record (k = 17, level 1)
+};
+constexpr size_t SCATTER_LDS_NARROW = offsetof(ScatterLds, dig);   // 72 KiB: two workgroups per CU
+constexpr size_t SCATTER_LDS_WIDE = sizeof(ScatterLds);            // 104 KiB
+
+// WIDE = the digit is kept in its own LDS array; otherwise the record parked in LDS still carries its
+// digit (digit << shift | rest fits 32 bits) and is masked on the way out.
+// `claim` != nullptr: the tile's run for digit d starts where a global cursor says (atomicAdd of the
+// run length), instead of at this workgroup's precomputed running offset L.run[d].  With `cap_end` too the
+// destinations have provisioned capacities (level 1, see kmer_fuse.hip): a run that would end beyond
+// cap_end[d] raises *overflow and is written to the `dump` area instead (one tile's worth of slots behind
+// the buckets), so nothing is ever stored outside its bucket; the host then repeats the level with exact sizes.
+// n_tile == ~0u: the number of records is not known to the caller; it is taken from the digit scan.
+//
+// `settle()` is called once the tile is parked, right before its runs are stored.  The callers use it to
+// take delivery of the NEXT tile's prefetched records at that point.  On this ISA loads and stores share one
+// in-order counter (vmcnt): a wait placed after the stores -- where the compiler would put it, at the top
+// of the next tile -- also waits for the stores to be acknowledged by HBM, a full round trip of ~8 us per
+// tile with nothing else in flight.  Waiting here costs nothing (the loads were issued a whole sort ago)
+// and leaves the stores in flight through the next tile's ranking and parking.
+template <typename RIN, bool WIDE, class Settle>
+__device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PER], const bool (&ok)[SC_PER], uint32_t n_tile,
+                                             uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out,
+                                             Settle &&settle, uint32_t *claim = nullptr, const uint32_t *__restrict__ cap_end = nullptr,
+                                             uint32_t dump = 0, uint32_t *overflow = nullptr) {
+    uint32_t dr[SC_PER];                                   // digit (9 bits) | rank inside the tile << 9
+#pragma unroll
+    for (int j = 0; j < SC_PER; j++) {
+        dr[j] = 0;
+        if (ok[j]) {
+            const uint32_t dg = (uint32_t)((uint64_t)r[j] >> shift) & (B - 1u);
+            dr[j] = dg | (atomicAdd(&L.hist[dg], 1u) << 9);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of hist[0..B) by the first B threads (B <= 512 <= SC_T)
+    uint32_t my_off = 0, claimed = 0;
+    {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        uint32_t v = threadIdx.x < B ? L.hist[threadIdx.x] : 0u, inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63) L.wsum[w] = inc;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (int i = 0; i < w; i++) pre += L.wsum[i];
+        my_off = pre + inc - v;
+        if (threadIdx.x < B) {
+            L.off[threadIdx.x] = my_off;
+            if (threadIdx.x == B - 1u) L.total = my_off + v;
+            // a claimed run start is only needed when the runs are written: the atomic's round trip to HBM
+            // overlaps the parking of the records below
+            if (claim) {
+                claimed = v ? atomicAdd(&claim[threadIdx.x], v) : 0u;
+                if (cap_end && v && claimed + v > cap_end[threadIdx.x]) {     // provisioned room exhausted (rare): park the run aside
+                    *overflow = 1u;
+                    claimed = dump + my_off;
+                }
+            } else { L.gbase[threadIdx.x] = L.run[threadIdx.x] - my_off; L.run[threadIdx.x] += v; }
+            L.hist[threadIdx.x] = 0;                          // ready for the next tile
+        }
+    }
+    __syncthreads();
+    if (n_tile == ~0u) n_tile = L.total;
+#pragma unroll
+    for (int j = 0; j < SC_PER; j++)
+        if (ok[j]) {
+            const uint32_t dg = dr[j] & 511u;
+            const uint32_t p = L.off[dg] + (dr[j] >> 9);
+            if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)dg; }
+            else L.rec[p] = (uint32_t)r[j];
+        }
+    if (claim && threadIdx.x < B) L.gbase[threadIdx.x] = claimed - my_off;   // sorted position p of digit d goes to p + gbase[d]
+    __syncthreads();
+    settle();
+    if (out16) {
+        // 16-bit records: each thread takes pairs of neighbours in sorted order and writes them as one
+        // dword when they fall in the same run and the destination is even (the common case)
+        uint16_t *o16 = reinterpret_cast<uint16_t *>(out);
+#pragma unroll
+        for (int j = 0; j < SC_PER / 2; j++) {
+            const uint32_t p = 2u * (threadIdx.x + j * SC_T);
+            if (p < n_tile) {
+                const uint32_t r0 = L.rec[p], r1 = p + 1 < n_tile ? L.rec[p + 1] : 0u;
+                const uint32_t d0 = WIDE ? L.dig[p] : (r0 >> shift) & (B - 1u);
+                const uint32_t d1 = p + 1 < n_tile ? (WIDE ? (uint32_t)L.dig[p + 1] : (r1 >> shift) & (B - 1u)) : ~0u;
+                const uint32_t dst0 = p + L.gbase[d0];
+                if (d0 == d1 && (dst0 & 1u) == 0u) {
+                    *reinterpret_cast<uint32_t *>(o16 + dst0) = (r0 & low_mask) | ((r1 & low_mask) << 16);
+                } else {
+                    o16[dst0] = (uint16_t)(r0 & low_mask);
+                    if (p + 1 < n_tile) o16[p + 1 + L.gbase[d1]] = (uint16_t)(r1 & low_mask);
+                }
+            }
+        }
+    } else {
+        // 32-bit records: neighbours in sorted order leave as one 8-byte store when they share a run
+        uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
+#pragma unroll
+        for (int j = 0; j < SC_PER / 2; j++) {
+            const uint32_t p = 2u * (threadIdx.x + j * SC_T);
+            if (p < n_tile) {
+                const uint32_t r0 = L.rec[p], r1 = p + 1 < n_tile ? L.rec[p + 1] : 0u;
+                const uint32_t d0 = WIDE ? L.dig[p] : (r0 >> shift) & (B - 1u);
+                const uint32_t d1 = p + 1 < n_tile ? (WIDE ? (uint32_t)L.dig[p + 1] : (r1 >> shift) & (B - 1u)) : ~0u;
+                const uint32_t dst0 = p + L.gbase[d0];
+                if (d0 == d1 && (dst0 & 1u) == 0u) {
+                    *reinterpret_cast<uint2 *>(o32 + dst0) = make_uint2(r0 & low_mask, r1 & low_mask);
+                } else {
+                    o32[dst0] = r0 & low_mask;
+                    if (p + 1 < n_tile) o32[p + 1 + L.gbase[d1]] = r1 & low_mask;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+
+}  // namespace pk

@@ -94,8 +94,7 @@ struct pk_indexer {
     int k = 0, device = 0;
     uint64_t n = 0;                  // 4^k
     hipStream_t stream = nullptr;
-    uint32_t *table32 = nullptr;     // counters while counting
-    uint8_t *table8 = nullptr;       // finished .kin image
+    uint8_t *table8 = nullptr;       // the .kin image
     Carry *carry = nullptr;
     unsigned long long *hist = nullptr;
     DevRec *recs = nullptr;
@@ -108,23 +107,21 @@ struct pk_indexer {
     uint32_t chunk_cap = 0;
     uint8_t *staging = nullptr;      // device copy of host-fed bytes
     uint64_t staging_cap = 0;
-    uint64_t bytes_fed = 0, since_clamp = 0, n_recs = 0;
+    uint64_t bytes_fed = 0, n_recs = 0;
     bool finished = false;
     hipEvent_t ev[12] = {};
-    double t_scan = 0, t_count = 0, t_final = 0, t_zero = 0, t_part = 0, t_bucket = 0;
-    int count_launches = 0;
-    bool table_fresh = true;         // partitioned mode: no feed has written the u8 table since the last reset
-    bool direct = false;             // PK_COUNT_MODE=direct: version-1 table update (global atomics on u32 counters)
-    uint8_t *ws = nullptr;           // partitioned mode workspace
+    double t_scan = 0, t_squeeze = 0, t_sort = 0, t_final = 0, t_zero = 0, t_part = 0, t_bucket = 0;
+    int feeds = 0, relayouts = 0;
+    bool table_fresh = true;         // no feed has written the u8 table since the last reset
+    uint8_t *ws = nullptr;           // workspace of the partition passes
     size_t ws_cap = 0;
 };
 
 static int ix_reset(pk_indexer *ix) {
     HIPCHK(hipSetDevice(ix->device));
     HIPCHK(hipEventRecord(ix->ev[6], ix->stream));
-    if (ix->direct) HIPCHK(hipMemsetAsync(ix->table32, 0, ix->n * sizeof(uint32_t), ix->stream));
-    // partitioned mode: the first feed writes every slice of the u8 table itself (k_bucket_count, fresh);
-    // the table is only zeroed here if nothing gets fed at all (see pk_indexer_finish)
+    // the first feed writes every slice of the u8 table itself (k_bucket_count, fresh); the table is only
+    // zeroed if nothing gets fed at all (see pk_indexer_finish)
     HIPCHK(hipEventRecord(ix->ev[7], ix->stream));
     Carry c;
     memset(&c, 0, sizeof c);
@@ -137,11 +134,11 @@ static int ix_reset(pk_indexer *ix) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ix->ev[6], ix->ev[7]));
     ix->t_zero = ms * 1e-3;
-    ix->bytes_fed = ix->since_clamp = ix->n_recs = 0;
+    ix->bytes_fed = ix->n_recs = 0;
     ix->finished = false;
     ix->table_fresh = true;
-    ix->t_scan = ix->t_count = ix->t_final = ix->t_part = ix->t_bucket = 0;
-    ix->count_launches = 0;
+    ix->t_scan = ix->t_squeeze = ix->t_sort = ix->t_final = ix->t_part = ix->t_bucket = 0;
+    ix->feeds = ix->relayouts = 0;
     return PK_OK;
 }
 
@@ -149,7 +146,7 @@ extern "C" void pk_indexer_destroy(pk_indexer *ix) {
     if (!ix) return;
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
-    hipFree(ix->table32); hipFree(ix->table8); hipFree(ix->carry); hipFree(ix->hist); hipFree(ix->recs);
+    hipFree(ix->table8); hipFree(ix->carry); hipFree(ix->hist); hipFree(ix->recs);
     hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state); hipFree(ix->t_l1); hipFree(ix->t_l2); hipFree(ix->staging); hipFree(ix->ws);
     for (auto &e : ix->ev) if (e) hipEventDestroy(e);
     if (ix->stream) hipStreamDestroy(ix->stream);
@@ -174,12 +171,10 @@ extern "C" int pk_indexer_create(pk_indexer **out, int k, int device) {
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     for (auto &ev : ix->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
-    const char *mode = getenv("PK_COUNT_MODE");
-    ix->direct = mode && strcmp(mode, "direct") == 0;
-    if (ix->direct && (e = hipMalloc(&ix->table32, ix->n * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(u32 table)");
     if ((e = hipMalloc(&ix->table8, std::max<uint64_t>(ix->n, 16))) != hipSuccess) return bail(e, "hipMalloc(u8 table)");
     if ((e = hipMalloc(&ix->carry, sizeof(Carry))) != hipSuccess) return bail(e, "hipMalloc(carry)");
     if ((e = hipMalloc(&ix->hist, 256 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(hist)");
+    part_set_attributes();                               // dynamic-LDS opt-ins, once per process and device
     rc = ix_reset(ix);
     if (rc) { std::string keep = g_err; pk_indexer_destroy(ix); g_err = keep; return rc; }
     *out = ix;
@@ -221,23 +216,14 @@ static int ensure_recs(pk_indexer *ix, uint64_t need) {
     return PK_OK;
 }
 
-extern "C" int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uint64_t n_bytes) {
-    if (!ix) return fail(PK_ERR_ARG, "null indexer");
-    if (ix->finished) return fail(PK_ERR_STATE, "indexer already finished; reset it first");
-    if (n_bytes == 0) return PK_OK;
-    if (!dev_fasta || ((uintptr_t)dev_fasta & 15u)) return fail(PK_ERR_ARG, "device FASTA pointer must be non-null and 16-byte aligned");
-    if (n_bytes > (1ULL << 40)) return fail(PK_ERR_ARG, "feed of %llu bytes too large; split it", (unsigned long long)n_bytes);
-    HIPCHK(hipSetDevice(ix->device));
-    if (n_bytes >= 0xFFFFFF00ULL) return fail(PK_ERR_ARG, "single feed must stay below 4 GiB");
-    // direct mode, u32 counters: clamp before any single address could wrap (one k-mer per byte at most)
-    if (ix->direct && ix->since_clamp + n_bytes >= 0xFFFFFF00ULL) {
-        launch_clamp32(ix->table32, ix->n, ix->stream);
-        ix->since_clamp = 0;
-    }
+// one feed of at most FEED_MAX bytes: structure pass -> squeeze -> bucket layout -> fused k-mer assembly + level-1
+// sort -> level 2 -> bucket count
+static const uint64_t FEED_MAX = 3ULL << 30;             // keeps every record index (capacity x 9/8) below 2^32
+
+static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
     const uint32_t n_chunks = (uint32_t)((n_bytes + CHUNK - 1) / CHUNK);
     int rc = ensure_chunks(ix, n_chunks);
     if (rc) return rc;
-    const uint8_t *f = (const uint8_t *)dev_fasta;
     HIPCHK(hipEventRecord(ix->ev[0], ix->stream));
     launch_chunk_l1(f, n_bytes, ix->c_l1, n_chunks, ix->stream);
     launch_scan_l1(ix->c_l1, n_chunks, ix->carry, ix->c_l1s, ix->t_l1, ix->stream);
@@ -250,37 +236,58 @@ extern "C" int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uin
     rc = ensure_recs(ix, n_recs);
     if (rc) return rc;
     ix->n_recs = n_recs;
-    float a = 0, b = 0, c = 0, d = 0;
-    if (ix->direct) {
-        HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
-        launch_count(f, n_bytes, ix->bytes_fed, ix->lane_state, ix->c_l2s, n_chunks, (uint32_t)ix->k, ix->table32, ix->recs, ix->recs_cap,
-                     ix->carry, ix->stream);
-        HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(ix->stream));
-    } else {
-        PartPlan pl = make_part_plan((uint32_t)ix->k, n_bytes);
-        PartWorkspace lay;
-        size_t need = part_workspace_bytes(pl, n_bytes, &lay);
-        if (need > ix->ws_cap) {
-            hipFree(ix->ws); ix->ws = nullptr; ix->ws_cap = 0;
-            HIPCHK(hipMalloc(&ix->ws, need));
-            ix->ws_cap = need;
-        }
-        HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
-        if (launch_partitioned(f, n_bytes, ix->bytes_fed, ix->lane_state, ix->c_l2s, pl, ix->ws, lay, ix->table8, ix->recs, ix->recs_cap,
-                               ix->carry, ix->stream, ix->ev[3], ix->ev[8], ix->table_fresh, ix->hist))
-            return fail(PK_ERR_HIP, "partition pipeline launch failed: %s", hipGetErrorString(hipGetLastError()));
-        ix->table_fresh = false;
-        HIPCHK(hipEventRecord(ix->ev[9], ix->stream));
-        HIPCHK(hipStreamSynchronize(ix->stream));
-        HIPCHK(hipEventElapsedTime(&c, ix->ev[3], ix->ev[8]));
-        HIPCHK(hipEventElapsedTime(&d, ix->ev[8], ix->ev[9]));
+    PartPlan pl = make_part_plan((uint32_t)ix->k, n_bytes);
+    PartWorkspace lay;
+    const size_t need = part_workspace_bytes(pl, n_bytes, &lay);
+    if (need > ix->ws_cap) {
+        hipFree(ix->ws); ix->ws = nullptr; ix->ws_cap = 0;
+        HIPCHK(hipMalloc(&ix->ws, need));
+        ix->ws_cap = need;
     }
+    HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
+    launch_squeeze(f, n_bytes, ix->bytes_fed, ix->lane_state, ix->c_l2s, (uint32_t)ix->k, n_chunks, pl.n_wg0, pl.G, (uint32_t *)(ix->ws + lay.codes),
+                   (uint32_t *)(ix->ws + lay.restarts), (uint32_t *)(ix->ws + lay.n_bases), ix->recs, ix->recs_cap, ix->carry, ix->stream);
+    HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
+    float a = 0, b = 0, c = 0, d = 0, e = 0;
+    // the level-1 buckets are laid out from a sample of the slots; if one of them runs out of room every later kernel
+    // returns untouched (flags[0]) and the passes behind the squeeze are repeated with exact sizes
+    for (uint32_t stride = pl.sample_stride;; stride = 1) {
+        if (launch_partitioned(ix->c_l2s, n_bytes, pl, stride, ix->ws, lay, ix->table8, ix->stream, ix->ev[10], ix->ev[11], ix->ev[8],
+                               ix->table_fresh, ix->hist))
+            return fail(PK_ERR_HIP, "partition pipeline launch failed: %s", hipGetErrorString(hipGetLastError()));
+        HIPCHK(hipEventRecord(ix->ev[9], ix->stream));
+        uint32_t flags[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(flags, ix->ws + lay.side_n + 8, sizeof flags, hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        HIPCHK(hipGetLastError());
+        if (!flags[0]) break;
+        if (stride == 1) return fail(PK_ERR_HIP, "level-1 buckets overflowed an exact layout (internal error)");
+        ix->relayouts++;
+    }
+    ix->table_fresh = false;
     HIPCHK(hipEventElapsedTime(&a, ix->ev[0], ix->ev[1]));
     HIPCHK(hipEventElapsedTime(&b, ix->ev[2], ix->ev[3]));
-    ix->t_scan += a * 1e-3; ix->t_count += b * 1e-3; ix->t_part += c * 1e-3; ix->t_bucket += d * 1e-3; ix->count_launches++;
-    ix->bytes_fed += n_bytes; ix->since_clamp += n_bytes;
+    HIPCHK(hipEventElapsedTime(&c, ix->ev[3], ix->ev[8]));
+    HIPCHK(hipEventElapsedTime(&d, ix->ev[8], ix->ev[9]));
+    HIPCHK(hipEventElapsedTime(&e, ix->ev[10], ix->ev[11]));
+    ix->t_scan += a * 1e-3; ix->t_squeeze += b * 1e-3; ix->t_part += c * 1e-3; ix->t_bucket += d * 1e-3; ix->t_sort += e * 1e-3;
+    ix->feeds++;
+    ix->bytes_fed += n_bytes;
+    return PK_OK;
+}
+
+extern "C" int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uint64_t n_bytes) {
+    if (!ix) return fail(PK_ERR_ARG, "null indexer");
+    if (ix->finished) return fail(PK_ERR_STATE, "indexer already finished; reset it first");
+    if (n_bytes == 0) return PK_OK;
+    if (!dev_fasta || ((uintptr_t)dev_fasta & 15u)) return fail(PK_ERR_ARG, "device FASTA pointer must be non-null and 16-byte aligned");
+    if (n_bytes > (1ULL << 40)) return fail(PK_ERR_ARG, "feed of %llu bytes too large; split it", (unsigned long long)n_bytes);
+    HIPCHK(hipSetDevice(ix->device));
+    const uint8_t *f = (const uint8_t *)dev_fasta;
+    for (uint64_t off = 0; off < n_bytes; off += FEED_MAX) {       // FEED_MAX is a multiple of 16: pieces stay aligned
+        int rc = feed_piece(ix, f + off, std::min(FEED_MAX, n_bytes - off));
+        if (rc) return rc;
+    }
     return PK_OK;
 }
 
@@ -310,14 +317,11 @@ extern "C" int pk_indexer_finish(pk_indexer *ix, uint64_t *num_kmers_out, uint64
     HIPCHK(hipSetDevice(ix->device));
     if (!ix->finished) {
         HIPCHK(hipEventRecord(ix->ev[4], ix->stream));
-        if (ix->direct) launch_finalize(ix->table32, ix->table8, ix->n, ix->hist, ix->stream);
-        else {
-            if (ix->table_fresh) {                           // nothing was fed: the table is all zero
-                HIPCHK(hipMemsetAsync(ix->table8, 0, std::max<uint64_t>(ix->n, 16), ix->stream));
-                ix->table_fresh = false;
-            }
-            // the value histogram was kept up to date by k_bucket_count / k_apply_side: no pass over the table
+        if (ix->table_fresh) {                               // nothing was fed: the table is all zero
+            HIPCHK(hipMemsetAsync(ix->table8, 0, std::max<uint64_t>(ix->n, 16), ix->stream));
+            ix->table_fresh = false;
         }
+        // the value histogram was kept up to date by k_bucket_count / k_apply_side: no pass over the table
         HIPCHK(hipEventRecord(ix->ev[5], ix->stream));
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ix->stream));
@@ -382,11 +386,11 @@ extern "C" int pk_indexer_table_slice_to_device(pk_indexer *ix, void *dev_dst, u
     return PK_OK;
 }
 
-extern "C" int pk_indexer_timings(pk_indexer *ix, double out[8]) {
+extern "C" int pk_indexer_timings(pk_indexer *ix, double out[10]) {
     if (!ix || !out) return fail(PK_ERR_ARG, "null argument");
-    for (int i = 0; i < 8; i++) out[i] = 0;
-    out[0] = ix->t_scan; out[1] = ix->t_count; out[2] = ix->t_final; out[3] = ix->t_zero; out[4] = (double)ix->count_launches;
-    out[5] = ix->t_part; out[6] = ix->t_bucket; out[7] = ix->direct ? 1.0 : 0.0;
+    for (int i = 0; i < 10; i++) out[i] = 0;
+    out[0] = ix->t_scan; out[1] = ix->t_squeeze; out[2] = ix->t_final; out[3] = ix->t_zero; out[4] = (double)ix->feeds;
+    out[5] = ix->t_part; out[6] = ix->t_bucket; out[7] = ix->t_sort; out[8] = (double)ix->relayouts;
     return PK_OK;
 }
 

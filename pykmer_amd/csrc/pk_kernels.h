@@ -30,32 +30,46 @@ void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, L1 *
 void launch_chunk_l2(const uint8_t *fasta, uint64_t n, const L1 *st1, L2 *chunk_l2, LaneState *lane_state, uint32_t n_chunks, uint32_t k,
                      hipStream_t s);
 void launch_scan_l2(const L2 *in, uint32_t n_chunks, Carry *carry, L2 *out, L2 *tile_ws, uint32_t k, hipStream_t s);
-void launch_count(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, uint32_t n_chunks,
-                  uint32_t k, uint32_t *table32, DevRec *recs, uint64_t recs_cap, Carry *carry, hipStream_t s);
-void launch_finalize(const uint32_t *table32, uint8_t *table8, uint64_t n, unsigned long long *hist, hipStream_t s);
 void launch_hist8(const uint8_t *table8, uint64_t n, unsigned long long *hist, hipStream_t s);
-void launch_clamp32(uint32_t *table32, uint64_t n, hipStream_t s);
 
-// kmer_part.hip -- partitioned table update (version 2)
+// kmer_pack.hip -- the packed stream: one slot per 16 KiB text chunk
+constexpr uint32_t SLOT_CODE_WORDS = 1024;   // 16384 bases x 2 bits
+constexpr uint32_t SLOT_RST_WORDS = 512;     // 16384 restart bits
+void launch_squeeze(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, uint32_t k,
+                    uint32_t n_chunks, uint32_t n_wg, uint32_t chunks_per_wg, uint32_t *codes, uint32_t *restarts, uint32_t *n_bases,
+                    DevRec *recs, uint64_t recs_cap, Carry *carry, hipStream_t s);
+
+// kmer_fuse.hip / kmer_part.hip -- partitioned table update
 struct PartPlan {
     uint32_t k, addr_bits;   // 2k
     uint32_t fb_bits;        // address bits inside a final bucket (<= 16)
     uint32_t b1, b2, B1, B2; // level-1 / level-2 digit widths and bucket counts
     uint32_t n_chunks;       // 16 KiB FASTA chunks in this feed
-    uint32_t n_wg0, G;       // walk workgroups and chunks per workgroup (rows of the level-1 histogram)
+    uint32_t n_wg0, G;       // persistent workgroups of the squeeze / sort kernels and chunks per workgroup
     uint64_t R2;             // records per level-2 workgroup
     uint32_t n_wg2_max;      // upper bound on level-2 workgroups
-    uint32_t dbg;            // PK_DEBUG_WALK ablation bits (timing diagnostics only; 0 in production)
+    uint32_t sample_stride;  // every how-manieth slot is tallied to size the level-1 buckets (1 = all: exact)
+    uint64_t capacity1;      // record slots for all level-1 buckets together (the dump area starts there)
 };
 struct PartWorkspace {       // byte offsets into one device allocation
-    size_t flat, cnt, hist1, rowoff1, bucket_base, wg2_start, col_tot, final_start, out1, hist2, rowoff2, out2, side, side_n, bucket_hist, fine_rows, fine_tot, cursor;
+    size_t codes, restarts, n_bases, sample_hist, bucket_base, bucket_end, compact_base, cursor1, cap_end, wg2_start, final_start, out1, hist2,
+        rowoff2, out2, side, side_n, bucket_hist, fine_rows, fine_tot, cursor;
     uint64_t side_cap;
 };
 PartPlan make_part_plan(uint32_t k, uint64_t n_bytes);
 size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace *lay);
-int launch_partitioned(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, const PartPlan &pl,
-                       uint8_t *ws, const PartWorkspace &lay, uint8_t *table8, DevRec *recs, uint64_t recs_cap, Carry *carry,
-                       hipStream_t s, hipEvent_t ev_walk_end, hipEvent_t ev_part_end, bool fresh, unsigned long long *hist);
+void part_set_attributes();
+void fuse_set_attributes();
+void launch_provision(const uint32_t *codes, const uint32_t *restarts, const uint32_t *n_bases, const L2 *st2, const PartPlan &pl,
+                      uint32_t stride, uint32_t capacity, uint32_t *sample_hist, uint32_t *bucket_base, uint32_t *cursor1,
+                      uint32_t *cap_end, uint32_t *flags, hipStream_t s);
+void launch_walk_sort(const uint32_t *codes, const uint32_t *restarts, const uint32_t *n_bases, const L2 *st2, const PartPlan &pl, void *out1,
+                      uint32_t *cursor1, const uint32_t *cap_end, uint32_t dump, uint32_t *flags, uint32_t *fine_rows,
+                      const uint32_t *bucket_base, uint32_t *bucket_end, uint32_t *compact_base, uint32_t *wg2_start,
+                      unsigned long long *side, unsigned long long *side_n, uint64_t side_cap, hipStream_t s);
+int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint32_t stride, uint8_t *ws, const PartWorkspace &lay, uint8_t *table8,
+                       hipStream_t s, hipEvent_t ev_sort_begin, hipEvent_t ev_sort_end, hipEvent_t ev_part_end, bool fresh,
+                       unsigned long long *hist);
 
 // gram_scan.hip
 // tables: device array of N device pointers, each n_slice bytes (16-byte aligned).  pair: device N*N u64,
