@@ -21,6 +21,7 @@
 // bucket that outgrows its room raises a flag (its runs go to a dump area, nothing is overwritten); every
 // later kernel of the feed then returns at once and the host repeats from here with stride 1, i.e. with
 // exact sizes.  Inputs below 1024 chunks are counted exactly straight away.
+#include <cstdlib>
 #include "part_common.h"
 
 namespace pk {
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(SC_T) void k_walk_sort(const uint32_t *__restrict__
                                                     uint32_t *__restrict__ cursor1, const uint32_t *__restrict__ cap_end, uint32_t dump,
                                                     uint32_t *__restrict__ flags, uint32_t *__restrict__ fine_rows,
                                                     uint32_t *__restrict__ sample_hist, unsigned long long *__restrict__ side,
-                                                    unsigned long long *__restrict__ side_n, uint64_t side_cap) {
+                                                    unsigned long long *__restrict__ side_n, uint64_t side_cap, uint32_t dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     ScatterLds &L = *reinterpret_cast<ScatterLds *>(smem);
     constexpr bool WIDE = sizeof(KT) == 8;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(SC_T) void k_walk_sort(const uint32_t *__restrict__
             a1 = miss ? canon : a1;
             nn = miss ? ((nn << 8) & 0xffff00u) : nn;
             r[j] = canon;
-            ok[j] = miss;
+            ok[j] = (dbg & 8u) ? has : miss;
             if (!COUNT && ev_n != 0u) hot_insert(hot, (uint64_t)ev_a, ev_n, side, side_n, side_cap);   // rare: leaving a tandem run
         }
         if (COUNT) {
@@ -144,10 +145,16 @@ __global__ __launch_bounds__(SC_T) void k_walk_sort(const uint32_t *__restrict__
                 if (ok[j]) atomicAdd(&L.run[(uint32_t)((uint64_t)r[j] >> shift) & (B - 1u)], 1u);
             continue;
         }
+        if (!(dbg & 2u)) {
         hot_insert_wave(&hot, (unsigned long long)a1, nn & 0xffu, side, side_n, side_cap);          // drain the lane's entries
         hot_insert_wave(&hot, (unsigned long long)a2, (nn >> 8) & 0xffu, side, side_n, side_cap);
         hot_insert_wave(&hot, (unsigned long long)a3, nn >> 16, side, side_n, side_cap);
-        if (tally_fine) {
+        }
+        if (dbg & 4u) { uint32_t x = 0;
+#pragma unroll
+            for (int j = 0; j < SC_PER; j++) x ^= ok[j] ? (uint32_t)r[j] : 0u;
+            if (x == 0x12345u) flags[1] = 1; continue; }
+        if (tally_fine && !(dbg & 1u)) {
 #pragma unroll
             for (int j = 0; j < SC_PER; j++)
                 if (ok[j]) atomicAdd(&fine[(uint32_t)((uint64_t)r[j] >> pl.fb_bits)], 1u);
@@ -249,11 +256,11 @@ void launch_provision(const uint32_t *codes, const uint32_t *restarts, const uin
     if (pl.k <= 15)
         hipLaunchKernelGGL((k_walk_sort<uint32_t, true>), dim3(grid), dim3(SC_T), SCATTER_LDS_NARROW, s, codes, restarts, n_bases, st2, pl, n_sampled,
                            stride, (void *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, flags, (uint32_t *)nullptr, sample_hist,
-                           (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint64_t)0);
+                           (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint64_t)0, getenv("PK_DBG") ? (uint32_t)atoi(getenv("PK_DBG")) : 0u);
     else
         hipLaunchKernelGGL((k_walk_sort<uint64_t, true>), dim3(grid), dim3(SC_T), SCATTER_LDS_WIDE, s, codes, restarts, n_bases, st2, pl, n_sampled,
                            stride, (void *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, flags, (uint32_t *)nullptr, sample_hist,
-                           (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint64_t)0);
+                           (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint64_t)0, getenv("PK_DBG") ? (uint32_t)atoi(getenv("PK_DBG")) : 0u);
     hipLaunchKernelGGL(k_provision, dim3(1), dim3(512), 0, s, (const uint32_t *)sample_hist, pl, n_sampled, stride, capacity, bucket_base, cursor1,
                        cap_end, flags);
 }
@@ -265,10 +272,10 @@ void launch_walk_sort(const uint32_t *codes, const uint32_t *restarts, const uin
     const size_t lds = fuse_lds(pl, fine_rows != nullptr);
     if (pl.k <= 15)
         hipLaunchKernelGGL((k_walk_sort<uint32_t, false>), dim3(pl.n_wg0), dim3(SC_T), lds, s, codes, restarts, n_bases, st2, pl, pl.n_chunks, 1u, out1,
-                           cursor1, cap_end, dump, flags, fine_rows, (uint32_t *)nullptr, side, side_n, side_cap);
+                           cursor1, cap_end, dump, flags, fine_rows, (uint32_t *)nullptr, side, side_n, side_cap, getenv("PK_DBG") ? (uint32_t)atoi(getenv("PK_DBG")) : 0u);
     else
         hipLaunchKernelGGL((k_walk_sort<uint64_t, false>), dim3(pl.n_wg0), dim3(SC_T), lds, s, codes, restarts, n_bases, st2, pl, pl.n_chunks, 1u, out1,
-                           cursor1, cap_end, dump, flags, fine_rows, (uint32_t *)nullptr, side, side_n, side_cap);
+                           cursor1, cap_end, dump, flags, fine_rows, (uint32_t *)nullptr, side, side_n, side_cap, 0u);
     hipLaunchKernelGGL(k_level1_finish, dim3(1), dim3(512), 0, s, (const uint32_t *)cursor1, bucket_base, cap_end, pl, bucket_end, compact_base,
                        wg2_start, (const uint32_t *)flags);
 }

@@ -51,6 +51,110 @@ __device__ __forceinline__ void lds_or_bits(uint32_t *dst, uint32_t at, unsigned
     }
 }
 
+// ------------------------------------------------------------------ clean pieces, four bytes at a time ----
+// A CLEAN piece holds nothing but sequence characters and line terminators, does not start inside a header
+// line and has no blank pending in front of it (the structure pass flags everything else): no record opens,
+// nothing is stripped, every byte above 13 is a sequence character.  Then the byte-wise machine is not needed:
+// per dword, SWAR tests give "terminator", "valid base" (either case; anything else maps to None, indexer.py:36-41)
+// and the 2-bit codes of all four bytes; a multiply gathers the per-byte flags into bit masks.  On the 64-bit masks
+//   restart bits   a valid base restarts the run iff a None character lies between it and the valid base
+//                  before it: adding the None mask into the mask of non-base positions ripples a carry up to
+//                  exactly those bases;
+//   window count   positions with no restart among the k-1 before them (shift-or smear), minus those the
+//                  incoming run is too short for;
+// and the few non-base positions (usually one line terminator) are deleted from the code / restart words one at a time.
+__device__ __forceinline__ uint32_t movemask4(uint32_t flags80) {       // 0x80-per-byte flags -> 4 bits, byte 0 lowest
+    return (flags80 * 0x00204081u) >> 28;
+}
+
+__device__ __forceinline__ void squeeze_clean(const uint8_t *lds, SeqWalker &wk, PieceBases &pb) {
+    const uint4 *mine = reinterpret_cast<const uint4 *>(lds + threadIdx.x * LDS_STRIDE);
+    uint32_t tm[2] = {0, 0}, vm[2] = {0, 0}, cw[4] = {0, 0, 0, 0};     // terminators, valid bases, codes (byte i -> bits 2i)
+#pragma unroll
+    for (int q = 0; q < PIECE / 16; q++) {
+        const uint4 v = mine[q];
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t w = w4[j];
+            const int d = q * 4 + j;                                     // dword index in the piece: bytes 4d .. 4d+3
+            // terminator (or fill past the end of the stream): bits 7-5 all clear -- a clean piece has no other byte below 0x20
+            const uint32_t hi3 = w | (w << 1) | (w << 2);
+            const uint32_t term = ~hi3 & 0x80808080u;
+            // the letter bits 2-1 stand for: 00 A, 01 C, 11 G, 10 T (either case)
+            const uint32_t s1 = w >> 1, s2 = w >> 2;
+            const uint32_t is_t = (s2 & ~s1) & 0x01010101u;
+            const uint32_t diff = (w & 0xD9D9D9D9u) ^ 0x41414141u ^ (is_t | (is_t << 4));   // zero byte <=> that letter
+            const uint32_t valid = swar_zero(diff);
+            const uint32_t b = s1 & 0x03030303u;
+            const uint32_t code = b ^ ((b >> 1) & 0x01010101u);          // A 0, C 1, G 2, T 3
+            const uint32_t code8 = (code * 0x01041040u) >> 24;           // byte i -> bits 2i .. 2i+1 of one byte
+            tm[d >> 3] |= movemask4(term) << (4 * (d & 7));
+            vm[d >> 3] |= movemask4(valid) << (4 * (d & 7));
+            cw[d >> 2] |= code8 << (8 * (d & 3));
+        }
+    }
+    const unsigned long long T = ((unsigned long long)tm[1] << 32) | tm[0];
+    unsigned long long V = ((unsigned long long)vm[1] << 32) | vm[0];
+    const unsigned long long S = ~T;                                      // sequence characters, valid or not
+    const unsigned long long none = S & ~V;                               // characters that map to None
+    const uint32_t n_seq = (uint32_t)__popcll(S);
+    wk.seq_acc += n_seq;                                                  // indexer.py:77: valid or not
+    const bool live = wk.rec != 0;                                        // text before the first header is dropped
+    // restart flags: carry from every None position through the non-base positions above it into the next base
+    unsigned long long F = ((~V) + none) & V;
+    if (wk.run == 0u) F |= V & (0ull - V);                                // the run was already broken when the piece began
+    const uint32_t nv = (uint32_t)__popcll(V);
+    // windows: compacted positions 0 .. nv-1; compact the restart flags first (delete the non-base positions)
+    unsigned long long c_lo = ((unsigned long long)cw[1] << 32) | cw[0], c_hi = ((unsigned long long)cw[3] << 32) | cw[2];
+    unsigned long long holes = V ? (~V & ((1ull << (63 - __builtin_clzll(V))) - 1ull)) : 0ull;   // below the highest base only
+    while (__any(holes != 0ull)) {
+        if (holes) {
+            const uint32_t p = (uint32_t)__builtin_ctzll(holes);
+            const unsigned long long low = (1ull << p) - 1ull;
+            F = (F & low) | ((F >> 1) & ~low);
+            holes = (holes >> 1) & ~low;
+            if (p < 32u) {
+                const unsigned long long low2 = (1ull << (2u * p)) - 1ull;
+                c_lo = (c_lo & low2) | (((c_lo >> 2) | (c_hi << 62)) & ~low2);
+                c_hi >>= 2;
+            } else {
+                const unsigned long long low2 = (1ull << (2u * (p - 32u))) - 1ull;
+                c_hi = (c_hi & low2) | ((c_hi >> 2) & ~low2);
+            }
+        }
+    }
+    // holes above the highest base were left where they are; clear everything past the nv bases
+    const unsigned long long keep = nv >= 64u ? ~0ull : ((1ull << nv) - 1ull);
+    F &= keep;
+    if (nv < 32u) { c_lo &= (1ull << (2u * nv)) - 1ull; c_hi = 0; }
+    else if (nv < 64u) c_hi &= (1ull << (2u * (nv - 32u))) - 1ull;
+    // valid windows ending in this piece (indexer.py:144): no restart among the k-1 positions behind the window's
+    // first base, and -- where no restart precedes -- enough bases carried in
+    const uint32_t km1 = wk.k - 1u;
+    unsigned long long X = 0;
+    {
+        const unsigned long long y1 = F | (F << 1), y2 = y1 | (y1 << 2), y3 = y2 | (y2 << 4), y4 = y3 | (y3 << 8);
+        uint32_t off = 0;
+        if (km1 >= 16u) X = y4;
+        else {
+            if (km1 & 8u) { X |= y3; off = 8; }
+            if (km1 & 4u) { X |= y2 << off; off += 4; }
+            if (km1 & 2u) { X |= y1 << off; off += 2; }
+            if (km1 & 1u) { X |= F << off; }
+        }
+    }
+    const uint32_t short_by = wk.run >= km1 ? 0u : km1 - wk.run;         // leading positions the carried run cannot complete
+    const unsigned long long lead = short_by >= 64u ? ~0ull : ((1ull << short_by) - 1ull);
+    // a restart inside the piece takes over from the carried run: positions at or above the first restart obey X only
+    const unsigned long long below_first = F ? ((F & (0ull - F)) - 1ull) : ~0ull;
+    const unsigned long long has = ~X & ~(lead & below_first) & keep;
+    wk.kmer_acc += live ? (uint64_t)__popcll(has) : 0ull;
+    pb.code_lo = live ? c_lo : 0ull; pb.code_hi = live ? c_hi : 0ull;
+    pb.restart = live ? F : 0ull;
+    pb.n = live ? nv : 0u;
+}
+
 __global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
                                                 const LaneState *__restrict__ lane_state, const L2 *__restrict__ chunk_l2_state,
                                                 uint32_t k, uint32_t n_chunks, uint32_t chunks_per_wg, uint32_t *__restrict__ codes,
@@ -78,15 +182,20 @@ __global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fast
         // exact parser state at this lane's first byte: chunk state . lane prefix (both from the structure pass)
         const LaneState lst = lane_state[(uint64_t)c * WG + threadIdx.x];
         const L2 st2 = l2_compose(chunk_l2_state[c], lane_state_l2(lst), km1);
-        wk.begin(lane_state_ls(lst), st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
+        const uint32_t ls_in = lane_state_ls(lst);
+        wk.begin(ls_in, st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
         PieceBases pb;
         pb.clear();
-        for_each_byte(lds, nb, [&](uint32_t i, uint32_t ch, bool act) {
-            uint32_t code;
-            bool rst;
-            const bool take = wk.step(i, ch, act, code, rst);
-            pb.push(take, code, rst);
-        });
+        if (__all(!lane_state_dirty(lst) && ls_in != LS_HEADER && st2.p_tail == 0)) {     // the common case: plain sequence lines
+            squeeze_clean(lds, wk, pb);
+        } else {
+            for_each_byte(lds, nb, [&](uint32_t i, uint32_t ch, bool act) {
+                uint32_t code;
+                bool rst;
+                const bool take = wk.step(i, ch, act, code, rst);
+                pb.push(take, code, rst);
+            });
+        }
         wk.flush_rec_wave();
         // where the lane's bases go in the chunk's slot: exclusive prefix of the counts over the workgroup
         uint32_t total;
