@@ -139,16 +139,46 @@ __global__ __launch_bounds__(SC_T) void k_walk_sort(const uint32_t *__restrict__
             ok[j] = (dbg & 8u) ? has : miss;
             if (!COUNT && ev_n != 0u) hot_insert(hot, (uint64_t)ev_a, ev_n, side, side_n, side_cap);   // rare: leaving a tandem run
         }
+        // ---- hot keys leave the thread.  Tandem runs span many lanes: a lane whose predecessor (the 16 bases before)
+        // ended with the same k-mers in its cache would emit them again -- once per lane instead of once per run.
+        // Where the predecessor saw repeats at all, first occurrences it already holds become tallies too.
+        {
+            const uint32_t prev_nn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nn, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 gets 0
+            if (__any(prev_nn != 0u)) {
+                KT p1, p2, p3;
+                if (sizeof(KT) == 4) {
+                    p1 = (KT)__builtin_amdgcn_update_dpp(-1, (int)a1, 0x138, 0xf, 0xf, false);
+                    p2 = (KT)__builtin_amdgcn_update_dpp(-1, (int)a2, 0x138, 0xf, 0xf, false);
+                    p3 = (KT)__builtin_amdgcn_update_dpp(-1, (int)a3, 0x138, 0xf, 0xf, false);
+                } else {
+                    auto shr1 = [](unsigned long long v) {
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+                        return ((unsigned long long)hi << 32) | lo;
+                    };
+                    p1 = (KT)shr1((unsigned long long)a1); p2 = (KT)shr1((unsigned long long)a2); p3 = (KT)shr1((unsigned long long)a3);
+                }
+                if (prev_nn != 0u) {
+#pragma unroll
+                    for (int j = 0; j < SC_PER; j++) {
+                        if (ok[j] && (r[j] == p1 || r[j] == p2 || r[j] == p3)) {
+                            ok[j] = false;
+                            if (!COUNT) hot_insert(hot, (uint64_t)r[j], 1u, side, side_n, side_cap);
+                        }
+                    }
+                }
+            }
+            if (!COUNT && __any(nn != 0u)) {                                                  // this lane's own repeat tallies
+                if (nn & 0xffu) hot_insert(hot, (uint64_t)a1, nn & 0xffu, side, side_n, side_cap);
+                if (nn & 0xff00u) hot_insert(hot, (uint64_t)a2, (nn >> 8) & 0xffu, side, side_n, side_cap);
+                if (nn >> 16) hot_insert(hot, (uint64_t)a3, nn >> 16, side, side_n, side_cap);
+            }
+        }
         if (COUNT) {
 #pragma unroll
             for (int j = 0; j < SC_PER; j++)
                 if (ok[j]) atomicAdd(&L.run[(uint32_t)((uint64_t)r[j] >> shift) & (B - 1u)], 1u);
             continue;
-        }
-        if (!(dbg & 2u)) {
-        hot_insert_wave(&hot, (unsigned long long)a1, nn & 0xffu, side, side_n, side_cap);          // drain the lane's entries
-        hot_insert_wave(&hot, (unsigned long long)a2, (nn >> 8) & 0xffu, side, side_n, side_cap);
-        hot_insert_wave(&hot, (unsigned long long)a3, nn >> 16, side, side_n, side_cap);
         }
         if (dbg & 4u) { uint32_t x = 0;
 #pragma unroll
