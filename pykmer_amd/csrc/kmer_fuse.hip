@@ -4,8 +4,8 @@
 // np.unique + the fragment scatter do in process_kmers (indexer.py:162-297).  Input is the packed stream
 // of kmer_pack.hip: per 16 KiB text chunk a slot of 2-bit codes and restart bits.  Because the stream
 // holds nothing but valid bases, the k-mer ending at base j is a fixed-offset bit field of two dwords --
-// no state is carried from thread to thread -- so a workgroup of 1024 threads takes one slot, 16 bases per
-// thread, and keeps its <= 16 K canonical k-mers IN REGISTERS: exactly the tile the LDS counting sort of
+// no state is carried from thread to thread -- so one workgroup takes one slot, 16 or 32 bases per thread,
+// and keeps its <= 16 K canonical k-mers IN REGISTERS: exactly the tile the LDS counting sort of
 // part_common.h wants.  The records never exist in HBM unsorted (round 1 wrote 2.8 GB of them and read
 // 3.3 GB back).
 //
@@ -15,13 +15,18 @@
 // The per-lane three-entry cache of recent k-mers (part_common.h, hot keys) keeps tandem repeats out of the
 // record stream as before.
 //
-// Where the runs go: level-1 bucket sizes are not known before the k-mers exist.  A sampling launch of the
-// same kernel (COUNT: every 16th slot, tally only) estimates them, k_provision lays the buckets out with
-// 12.5 % + 4096 records of slack each, and the sort claims room for every run from per-bucket cursors.  A
-// bucket that outgrows its room raises a flag (its runs go to a dump area, nothing is overwritten); every
+// Shape: k <= 15 runs 512 threads x 32 bases with 72 KiB of LDS, so TWO workgroups share a CU and one's
+// k-mer assembly (vector ALU) overlaps the other's ranking / parking / run writes (LDS, HBM) -- with one
+// 1024-thread workgroup per CU the phases ran back to back (2.4 ms instead of W + sort overlapped).  k = 17
+// (64-bit k-mers, digit kept beside the record: 104 KiB) stays at 1024 x 16, one workgroup per CU.
+//
+// Where the runs go: bucket sizes are not known before the k-mers exist.  A sampling launch of the same
+// kernel (COUNT: every 16th slot, tally only) estimates the size of every FINAL bucket (top b1+b2 address
+// bits, <= 2^14 of them; k = 17: of every level-1 bucket), k_provision lays the buckets of both levels out
+// with 12.5 % + a constant of slack each, and the sorts claim room for every run from per-bucket cursors.
+// A bucket that outgrows its room raises a flag (its runs go to a dump area, nothing is overwritten); every
 // later kernel of the feed then returns at once and the host repeats from here with stride 1, i.e. with
 // exact sizes.  Inputs below 1024 chunks are counted exactly straight away.
-#include <cstdlib>
 #include "part_common.h"
 
 namespace pk {
@@ -43,28 +48,41 @@ __device__ __forceinline__ uint32_t smear_up(uint32_t x, uint32_t n) {
     return acc;
 }
 
-template <typename KT, bool COUNT>
-__global__ __launch_bounds__(SC_T) void k_walk_sort(const uint32_t *__restrict__ codes, const uint32_t *__restrict__ restarts,
-                                                    const uint32_t *__restrict__ n_bases, const L2 *__restrict__ chunk_l2_state,
-                                                    PartPlan pl, uint32_t n_items, uint32_t stride, void *__restrict__ out,
-                                                    uint32_t *__restrict__ cursor1, const uint32_t *__restrict__ cap_end, uint32_t dump,
-                                                    uint32_t *__restrict__ flags, uint32_t *__restrict__ fine_rows,
-                                                    uint32_t *__restrict__ sample_hist, unsigned long long *__restrict__ side,
-                                                    unsigned long long *__restrict__ side_n, uint64_t side_cap, uint32_t dbg) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    ScatterLds &L = *reinterpret_cast<ScatterLds *>(smem);
+template <typename T>
+__device__ __forceinline__ T wave_shr1(T v, T fill) {                   // lane l gets lane l-1's value, lane 0 gets `fill`
+    if (sizeof(T) == 4) return (T)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)fill, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)((unsigned long long)fill >> 32),
+                                                              (int)(uint32_t)((unsigned long long)v >> 32), 0x138, 0xf, 0xf, false);
+    return (T)(((unsigned long long)hi << 32) | lo);
+}
+
+// NT threads, PER bases each (NT * PER = 16384 = one slot); NB = LDS room for level-1 digits; HS = hot-key slots.
+// COUNT: tally only -- `tally` counters in LDS ([n_tally], the final-bucket digit where there are two levels and
+// <= 2^14 final buckets, the level-1 digit otherwise), written out as one row per workgroup.
+template <typename KT, bool COUNT, int NT, int PER, int NB, uint32_t HS>
+__global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict__ codes, const uint32_t *__restrict__ restarts,
+                                                  const uint32_t *__restrict__ n_bases, const L2 *__restrict__ chunk_l2_state,
+                                                  PartPlan pl, uint32_t n_items, uint32_t stride, void *__restrict__ out,
+                                                  uint32_t *__restrict__ cursor1, const uint32_t *__restrict__ cap_end, uint32_t dump,
+                                                  uint32_t *__restrict__ flags, uint32_t tally_shift, uint32_t n_tally,
+                                                  uint32_t *__restrict__ tally_rows, unsigned long long *__restrict__ side,
+                                                  unsigned long long *__restrict__ side_n, uint64_t side_cap) {
+    static_assert(NT * PER == TILE && PER % 16 == 0, "one slot per workgroup");
+    constexpr int NW = PER / 16;                                          // code dwords per thread
     constexpr bool WIDE = sizeof(KT) == 8;
-    uint32_t *fine = reinterpret_cast<uint32_t *>(smem + (WIDE ? SCATTER_LDS_WIDE : SCATTER_LDS_NARROW));   // [B1 * B2] when fine_rows
-    __shared__ HotTable hot;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    ScatterLdsT<NB> &L = *reinterpret_cast<ScatterLdsT<NB> *>(smem);
+    uint32_t *tally = reinterpret_cast<uint32_t *>(smem);                 // COUNT only: the sort's LDS is not used then
+    __shared__ HotTable<COUNT ? 2u : HS> hot;
     const uint32_t k = pl.k, km1 = k - 1;
-    const uint32_t n_fine = pl.B1 * pl.B2;
-    const bool tally_fine = !COUNT && fine_rows != nullptr;
-    if (!COUNT) {
-        for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += SC_T) { hot.key[i] = 0ull; hot.val[i] = 0u; }
+    if (COUNT) {
+        for (uint32_t i = threadIdx.x; i < n_tally; i += NT) tally[i] = 0u;
+    } else {
+        for (uint32_t i = threadIdx.x; i < HS; i += NT) { hot.key[i] = 0ull; hot.val[i] = 0u; }
         if (threadIdx.x == 0) hot.used = 0;
-        if (tally_fine) for (uint32_t i = threadIdx.x; i < n_fine; i += SC_T) fine[i] = 0u;
+        for (uint32_t i = threadIdx.x; i < NB; i += NT) { L.hist[i] = 0; L.run[i] = 0; }
     }
-    if (threadIdx.x < 512) { L.hist[threadIdx.x] = 0; L.run[threadIdx.x] = 0; }
     const uint32_t B = pl.B1, shift = pl.addr_bits - pl.b1;
     const uint32_t low_mask = shift >= 32 ? 0xffffffffu : ((1u << shift) - 1u);
     const bool out16 = pl.b2 == 0;
@@ -79,88 +97,90 @@ __global__ __launch_bounds__(SC_T) void k_walk_sort(const uint32_t *__restrict__
         const uint32_t c = COUNT ? it * stride : it;
         const uint32_t nb = n_bases[c];                                   // uniform
         if (nb == 0) continue;
-        // ---- this thread's 16 bases, the 16 before them, and the restart bits of both
+        // ---- this thread's PER bases (NW code dwords), the 16 before them, and the restart bits of all of them
         const uint32_t *cw = codes + (uint64_t)c * SLOT_CODE_WORDS;
         const uint32_t *rw = restarts + (uint64_t)c * SLOT_RST_WORDS;
-        const bool live = 16u * t < nb;
-        uint32_t cur = 0, prev = 0, rr = 0;
+        const bool live = (uint32_t)PER * t < nb;
+        uint32_t cur[NW], prev0 = 0, rbits[NW];                           // rbits[w]: restart bits of the 16 bases before word w (low half) and of word w (high half)
+#pragma unroll
+        for (int w = 0; w < NW; w++) { cur[w] = 0; rbits[w] = 0; }
         if (live) {
-            cur = cw[t];
-            const uint32_t r_here = rw[t >> 1];
+#pragma unroll
+            for (int w = 0; w < NW; w++) cur[w] = cw[NW * t + w];
+            if (NW == 2) {
+                const uint32_t r_here = rw[t], r_before = t ? rw[t - 1] : 0u;
+                rbits[0] = (r_here << 16) | (r_before >> 16);
+                rbits[NW - 1] = r_here;
+            } else {
+                const uint32_t r_here = rw[t >> 1], r_before = t > 1 ? rw[(t >> 1) - 1] : 0u;
+                rbits[0] = (t & 1u) ? r_here : ((r_here << 16) | (r_before >> 16));
+            }
             if (t == 0) {
                 // the k-1 bases in front of the slot: the chunk's start state (newest base lowest) in stream order
                 const L2 st = chunk_l2_state[c];
                 const uint32_t len = l2_len(st);
-                prev = revpairs32(st.bits);
-                rr = r_here << 16;
-                if (len < km1) rr |= 1u << (16u - len);                   // nothing older than those `len` bases may be used
+                prev0 = revpairs32(st.bits);
+                rbits[0] &= 0xffff0000u;
+                if (len < km1) rbits[0] |= 1u << (16u - len);             // nothing older than those `len` bases may be used
             } else {
-                prev = cw[t - 1];
-                rr = (t & 1u) ? r_here : ((r_here << 16) | (rw[(t >> 1) - 1] >> 16));
+                prev0 = cw[NW * t - 1];
             }
         }
-        const uint32_t cnt = live ? min(16u, nb - 16u * t) : 0u;
-        // window ending at base j (bit 16 + j of rr) is void iff a restart lies among the k-1 bases after its first
-        const uint32_t hasmask = ~(smear_up(rr, km1) >> 16) & ((1u << cnt) - 1u);
-        const uint32_t fprev = revpairs32(prev), fcur = revpairs32(cur);
-        const unsigned long long fwd64 = ((unsigned long long)fprev << 32) | fcur;          // first base highest
-        const unsigned long long rev64 = ~(((unsigned long long)cur << 32) | prev);         // complemented, first base lowest
-        const uint32_t rev_sh0 = 2u * (17u - k);                                             // + 2j per base; < 64 for every odd k <= 17
+        const uint32_t n_mine = live ? min((uint32_t)PER, nb - (uint32_t)PER * t) : 0u;
 
-        KT r[SC_PER];
-        bool ok[SC_PER];
+        KT r[PER];
+        bool ok[PER];
         // The lane remembers its last three distinct k-mers.  A k-mer is emitted the first time it is seen;
         // seeing it again while remembered (tandem repeats of period 1-3: the contended buckets) only
         // bumps a counter, which goes to the workgroup's LDS table when the entry is evicted or the
-        // thread's 16 bases end.  Either route counts each k-mer exactly once.  a1, a2, a3 are pairwise
+        // thread's bases end.  Either route counts each k-mer exactly once.  a1, a2, a3 are pairwise
         // distinct (an entry is only ever inserted on a miss; the initial ~0 is no k-mer), so at most one
         // compare hits.  The three counters share one register: n1 | n2 << 8 | n3 << 16.
         KT a1 = ~(KT)0, a2 = ~(KT)0, a3 = ~(KT)0;
         uint32_t nn = 0;
 #pragma unroll
-        for (int j = 0; j < SC_PER; j++) {
-            KT f;
-            if (sizeof(KT) == 4) f = (KT)__builtin_amdgcn_alignbit(fprev, fcur, 2u * (15u - j)) & mask;
-            else f = (KT)(fwd64 >> (2u * (15u - j))) & mask;
-            const KT rv = (KT)(rev64 >> (rev_sh0 + 2u * j)) & mask;
-            const KT canon = f < rv ? f : rv;                                               // indexer.py:341
-            const bool has = (hasmask >> j) & 1u;
-            const bool e1 = canon == a1, e2 = canon == a2, e3 = canon == a3;
-            const bool h1 = has & e1, h2 = has & e2, h3 = has & e3;
-            const bool miss = has & !e1 & !e2 & !e3;
-            nn += h1 ? 1u : (h2 ? 0x100u : (h3 ? 0x10000u : 0u));
-            const uint32_t ev_n = miss ? (nn >> 16) : 0u;
-            const KT ev_a = a3;
-            a3 = miss ? a2 : a3;
-            a2 = miss ? a1 : a2;
-            a1 = miss ? canon : a1;
-            nn = miss ? ((nn << 8) & 0xffff00u) : nn;
-            r[j] = canon;
-            ok[j] = (dbg & 8u) ? has : miss;
-            if (!COUNT && ev_n != 0u) hot_insert(hot, (uint64_t)ev_a, ev_n, side, side_n, side_cap);   // rare: leaving a tandem run
+        for (int w = 0; w < NW; w++) {
+            const uint32_t prev = w ? cur[w ? w - 1 : 0] : prev0;
+            const uint32_t cnt = n_mine > 16u * w ? min(16u, n_mine - 16u * w) : 0u;
+            // window ending at base j of this word (bit 16 + j of rbits) is void iff a restart lies among the k-1 bases after its first
+            const uint32_t hasmask = ~(smear_up(rbits[w], km1) >> 16) & ((1u << cnt) - 1u);
+            const uint32_t fprev = revpairs32(prev), fcur = revpairs32(cur[w]);
+            const unsigned long long fwd64 = ((unsigned long long)fprev << 32) | fcur;      // first base highest
+            const unsigned long long rev64 = ~(((unsigned long long)cur[w] << 32) | prev);  // complemented, first base lowest
+            const uint32_t rev_sh0 = 2u * (17u - k);                                         // + 2j per base; < 64 for every odd k <= 17
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                KT f;
+                if (sizeof(KT) == 4) f = (KT)__builtin_amdgcn_alignbit(fprev, fcur, 2u * (15u - j)) & mask;
+                else f = (KT)(fwd64 >> (2u * (15u - j))) & mask;
+                const KT rv = (KT)(rev64 >> (rev_sh0 + 2u * j)) & mask;
+                const KT canon = f < rv ? f : rv;                                           // indexer.py:341
+                const bool has = (hasmask >> j) & 1u;
+                const bool e1 = canon == a1, e2 = canon == a2, e3 = canon == a3;
+                const bool h1 = has & e1, h2 = has & e2, h3 = has & e3;
+                const bool miss = has & !e1 & !e2 & !e3;
+                nn += h1 ? 1u : (h2 ? 0x100u : (h3 ? 0x10000u : 0u));
+                const uint32_t ev_n = miss ? (nn >> 16) : 0u;
+                const KT ev_a = a3;
+                a3 = miss ? a2 : a3;
+                a2 = miss ? a1 : a2;
+                a1 = miss ? canon : a1;
+                nn = miss ? ((nn << 8) & 0xffff00u) : nn;
+                r[16 * w + j] = canon;
+                ok[16 * w + j] = miss;
+                if (!COUNT && ev_n != 0u) hot_insert(hot, (uint64_t)ev_a, ev_n, side, side_n, side_cap);   // rare: leaving a tandem run
+            }
         }
-        // ---- hot keys leave the thread.  Tandem runs span many lanes: a lane whose predecessor (the 16 bases before)
+        // ---- hot keys leave the thread.  Tandem runs span many lanes: a lane whose predecessor (the bases before)
         // ended with the same k-mers in its cache would emit them again -- once per lane instead of once per run.
         // Where the predecessor saw repeats at all, first occurrences it already holds become tallies too.
         {
-            const uint32_t prev_nn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nn, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 gets 0
+            const uint32_t prev_nn = wave_shr1<uint32_t>(nn, 0u);
             if (__any(prev_nn != 0u)) {
-                KT p1, p2, p3;
-                if (sizeof(KT) == 4) {
-                    p1 = (KT)__builtin_amdgcn_update_dpp(-1, (int)a1, 0x138, 0xf, 0xf, false);
-                    p2 = (KT)__builtin_amdgcn_update_dpp(-1, (int)a2, 0x138, 0xf, 0xf, false);
-                    p3 = (KT)__builtin_amdgcn_update_dpp(-1, (int)a3, 0x138, 0xf, 0xf, false);
-                } else {
-                    auto shr1 = [](unsigned long long v) {
-                        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
-                        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
-                        return ((unsigned long long)hi << 32) | lo;
-                    };
-                    p1 = (KT)shr1((unsigned long long)a1); p2 = (KT)shr1((unsigned long long)a2); p3 = (KT)shr1((unsigned long long)a3);
-                }
+                const KT p1 = wave_shr1<KT>(a1, ~(KT)0), p2 = wave_shr1<KT>(a2, ~(KT)0), p3 = wave_shr1<KT>(a3, ~(KT)0);
                 if (prev_nn != 0u) {
 #pragma unroll
-                    for (int j = 0; j < SC_PER; j++) {
+                    for (int j = 0; j < PER; j++) {
                         if (ok[j] && (r[j] == p1 || r[j] == p2 || r[j] == p3)) {
                             ok[j] = false;
                             if (!COUNT) hot_insert(hot, (uint64_t)r[j], 1u, side, side_n, side_cap);
@@ -176,36 +196,27 @@ __global__ __launch_bounds__(SC_T) void k_walk_sort(const uint32_t *__restrict__
         }
         if (COUNT) {
 #pragma unroll
-            for (int j = 0; j < SC_PER; j++)
-                if (ok[j]) atomicAdd(&L.run[(uint32_t)((uint64_t)r[j] >> shift) & (B - 1u)], 1u);
+            for (int j = 0; j < PER; j++)
+                if (ok[j]) atomicAdd(&tally[(uint32_t)((uint64_t)r[j] >> tally_shift)], 1u);
             continue;
         }
-        if (dbg & 4u) { uint32_t x = 0;
-#pragma unroll
-            for (int j = 0; j < SC_PER; j++) x ^= ok[j] ? (uint32_t)r[j] : 0u;
-            if (x == 0x12345u) flags[1] = 1; continue; }
-        if (tally_fine && !(dbg & 1u)) {
-#pragma unroll
-            for (int j = 0; j < SC_PER; j++)
-                if (ok[j]) atomicAdd(&fine[(uint32_t)((uint64_t)r[j] >> pl.fb_bits)], 1u);
-        }
-        scatter_tile<KT, WIDE>(L, r, ok, ~0u, shift, B, low_mask, out16, out, no_settle, cursor1, cap_end, dump, flags);
-        if (hot.used >= HOT_SLOTS / 2) hot_flush(hot, side, side_n, side_cap);   // uniform: read after the barrier that ends the tile
+        scatter_tile<KT, WIDE, NT>(L, r, ok, ~0u, shift, B, low_mask, out16, out, no_settle, cursor1, cap_end, dump, flags);
+        if (hot.used >= HS / 2) hot_flush(hot, side, side_n, side_cap);   // uniform: read after the barrier that ends the tile
     }
     if (COUNT) {
         __syncthreads();
-        if (threadIdx.x < B && L.run[threadIdx.x]) atomicAdd(&sample_hist[threadIdx.x], L.run[threadIdx.x]);
+        for (uint32_t i = threadIdx.x; i < n_tally; i += NT) tally_rows[(uint64_t)blockIdx.x * n_tally + i] = tally[i];
         return;
     }
     hot_flush(hot, side, side_n, side_cap);
-    if (tally_fine) {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n_fine; i += SC_T) fine_rows[(uint64_t)blockIdx.x * n_fine + i] = fine[i];
-    }
 }
 
 // ------------------------------------------------------------------ bucket layout ---------------
-__device__ __forceinline__ uint32_t block_excl_scan_512(uint32_t v, uint32_t *wsum, uint32_t &total) {
+// One workgroup of 1024 threads.  `tot` holds the sampled tallies: of the final buckets (n_tally = B1 * B2 > B1) or
+// of the level-1 buckets (n_tally = B1).  Room for a bucket of estimated size e: e + e/8 + slack (stride 1: the
+// tally itself, which is exact or an over-count).  With final tallies both levels are laid out: final bucket
+// starts + write cursors + limits, and the level-1 buckets from the sums of their final buckets' estimates.
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *wsum, uint32_t &total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t inc = v;
 #pragma unroll
@@ -215,98 +226,133 @@ __device__ __forceinline__ uint32_t block_excl_scan_512(uint32_t v, uint32_t *ws
     __syncthreads();
     uint32_t pre = 0;
     total = 0;
-    for (int i = 0; i < 8; i++) { if (i < w) pre += wsum[i]; total += wsum[i]; }
+    for (int i = 0; i < 16; i++) { if (i < w) pre += wsum[i]; total += wsum[i]; }
     return pre + inc - v;
 }
 
-// one workgroup, one thread per level-1 bucket (B1 <= 512): room for every bucket from the sampled tallies
-__global__ __launch_bounds__(512) void k_provision(const uint32_t *__restrict__ sample_hist, PartPlan pl, uint32_t n_sampled,
-                                                   uint32_t stride, uint32_t capacity, uint32_t *__restrict__ bucket_base,
-                                                   uint32_t *__restrict__ cursor1, uint32_t *__restrict__ cap_end, uint32_t *flags) {
-    __shared__ uint32_t wsum[8];
-    const uint32_t d = threadIdx.x;
-    uint32_t room = 0;
-    if (d < pl.B1) {
-        const unsigned long long h = sample_hist[d];
-        if (stride == 1) room = (uint32_t)h;                                                // exact
-        else {
-            const unsigned long long est = (h * pl.n_chunks + n_sampled - 1) / n_sampled;
-            room = (uint32_t)(est + est / 8 + 4096);
-        }
-        room = (room + 3u) & ~3u;                                                           // bucket starts stay 16-byte aligned
+__device__ __forceinline__ uint32_t room_for(unsigned long long h, uint32_t n_chunks, uint32_t n_sampled, uint32_t stride, uint32_t slack) {
+    if (stride == 1) return (uint32_t)h;
+    const unsigned long long est = (h * n_chunks + n_sampled - 1) / n_sampled;
+    return (uint32_t)(est + est / 8 + slack);
+}
+
+__global__ __launch_bounds__(1024) void k_provision(const uint32_t *__restrict__ tot, uint32_t n_tally, PartPlan pl, uint32_t n_sampled,
+                                                    uint32_t stride, uint32_t *__restrict__ bucket_base, uint32_t *__restrict__ cursor1,
+                                                    uint32_t *__restrict__ cap_end, uint32_t *__restrict__ final_start,
+                                                    uint32_t *__restrict__ cursor2, uint32_t *__restrict__ cap2_end, uint32_t *flags) {
+    __shared__ uint32_t wsum[16];
+    __shared__ unsigned long long sum1[512];                // sampled tallies per level-1 bucket
+    const uint32_t B1 = pl.B1;
+    const bool two = n_tally > B1;                          // final-bucket tallies: lay out level 2 as well
+    for (uint32_t i = threadIdx.x; i < 512; i += 1024) sum1[i] = 0ull;
+    __syncthreads();
+    // final buckets: each thread takes `per` consecutive ones (<= 16)
+    const uint32_t per = (n_tally + 1023u) / 1024u;
+    const uint32_t lo = min(threadIdx.x * per, n_tally), hi = min(lo + per, n_tally);
+    uint32_t room_sum = 0;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t h = tot[i];
+        if (two) room_sum += (room_for(h, pl.n_chunks, n_sampled, stride, 2048u) + 7u) & ~7u;   // 16-bit records: starts stay 16-byte aligned
+        if (h) atomicAdd(&sum1[two ? (i >> pl.b2) : i], (unsigned long long)h);
     }
-    uint32_t total;
-    const uint32_t base = block_excl_scan_512(room, wsum, total);
-    if (d < pl.B1) { bucket_base[d] = base; cursor1[d] = base; cap_end[d] = base + room; }
-    if (d == 0) {
-        bucket_base[pl.B1] = total;
-        if (total > capacity) flags[0] = 1u;                                                // cannot happen with the bounds of part_workspace_bytes; be loud if it does
+    if (two) {
+        uint32_t total2;
+        uint32_t a = block_excl_scan_1024(room_sum, wsum, total2);
+        for (uint32_t i = lo; i < hi; i++) {
+            const uint32_t room = (room_for(tot[i], pl.n_chunks, n_sampled, stride, 2048u) + 7u) & ~7u;
+            final_start[i] = a; cursor2[i] = a; cap2_end[i] = a + room;
+            a += room;
+        }
+        if (threadIdx.x == 1023) final_start[n_tally] = a;
+        if (threadIdx.x == 0 && (uint64_t)total2 > pl.capacity2) flags[0] = 1u;
+    }
+    __syncthreads();
+    uint32_t room1 = 0;
+    if (threadIdx.x < B1) room1 = (room_for(sum1[threadIdx.x], pl.n_chunks, n_sampled, stride, 4096u) + 3u) & ~3u;   // 16-byte aligned starts
+    uint32_t total1;
+    const uint32_t base = block_excl_scan_1024(room1, wsum, total1);
+    if (threadIdx.x < B1) { bucket_base[threadIdx.x] = base; cursor1[threadIdx.x] = base; cap_end[threadIdx.x] = base + room1; }
+    if (threadIdx.x == 0) {
+        bucket_base[B1] = total1;
+        if ((uint64_t)total1 > pl.capacity1) flags[0] = 1u;               // cannot happen with the bounds of make_part_plan; be loud if it does
     }
 }
 
 // after the level-1 sort: how full every bucket got, the level-2 work split (bucket d gets ceil(n_d / R2)
 // workgroups) and, for the layouts that are compact again from here on, the exclusive scan of the sizes
-__global__ __launch_bounds__(512) void k_level1_finish(const uint32_t *__restrict__ cursor1, const uint32_t *__restrict__ bucket_base,
-                                                       const uint32_t *__restrict__ cap_end, PartPlan pl, uint32_t *__restrict__ bucket_end,
-                                                       uint32_t *__restrict__ compact_base, uint32_t *__restrict__ wg2_start,
-                                                       const uint32_t *__restrict__ flags) {
-    __shared__ uint32_t wsum[8];
+__global__ __launch_bounds__(1024) void k_level1_finish(const uint32_t *__restrict__ cursor1, const uint32_t *__restrict__ bucket_base,
+                                                        const uint32_t *__restrict__ cap_end, PartPlan pl, uint32_t *__restrict__ bucket_end,
+                                                        uint32_t *__restrict__ compact_base, uint32_t *__restrict__ wg2_start,
+                                                        const uint32_t *__restrict__ flags) {
+    __shared__ uint32_t wsum[16];
     if (flags[0]) return;
     const uint32_t d = threadIdx.x, B1 = pl.B1;
     uint32_t size = 0;
     if (d < B1) size = min(cursor1[d], cap_end[d]) - bucket_base[d];
     const uint32_t g = (uint32_t)(((uint64_t)size + pl.R2 - 1) / pl.R2);
     uint32_t sum_n, sum_g;
-    const uint32_t cb = block_excl_scan_512(size, wsum, sum_n);
-    const uint32_t ws = block_excl_scan_512(g, wsum, sum_g);
+    const uint32_t cb = block_excl_scan_1024(size, wsum, sum_n);
+    const uint32_t ws = block_excl_scan_1024(g, wsum, sum_g);
     if (d < B1) { bucket_end[d] = bucket_base[d] + size; compact_base[d] = cb; wg2_start[d] = ws; }
     if (d == 0) { compact_base[B1] = sum_n; wg2_start[B1] = sum_g; }
 }
 
-// ------------------------------------------------------------------ launchers -------------------
-static size_t fuse_lds(const PartPlan &pl, bool fine) {
-    const size_t base = pl.k > 15 ? SCATTER_LDS_WIDE : SCATTER_LDS_NARROW;
-    return base + (fine ? (size_t)pl.B1 * pl.B2 * 4 : 0);
+// column sums of the per-workgroup tally rows of the sampling launch
+__global__ __launch_bounds__(256) void k_tally_sum(const uint32_t *__restrict__ rows, uint32_t n_rows, uint32_t n_cols, uint32_t *__restrict__ tot) {
+    const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+    if (col >= n_cols) return;
+    uint32_t acc = 0;
+    for (uint32_t r = blockIdx.y; r < n_rows; r += gridDim.y) acc += rows[(uint64_t)r * n_cols + col];
+    if (acc) atomicAdd(&tot[col], acc);
 }
+
+// ------------------------------------------------------------------ launchers -------------------
+// k <= 15: 512 threads x 32 bases, 128 level-1 digits at most, 512 hot-key slots -> 72 KiB, two workgroups per CU
+typedef ScatterLdsT<128> FuseLdsNarrow;
+constexpr size_t FUSE_LDS_NARROW = offsetof(FuseLdsNarrow, dig);
 
 void fuse_set_attributes() {
-    hipFuncSetAttribute((const void *)k_walk_sort<uint32_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SCATTER_LDS_NARROW + 65536));
-    hipFuncSetAttribute((const void *)k_walk_sort<uint32_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
-    hipFuncSetAttribute((const void *)k_walk_sort<uint64_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_WIDE);
-    hipFuncSetAttribute((const void *)k_walk_sort<uint64_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_WIDE);
+    hipFuncSetAttribute((const void *)k_walk_sort<uint32_t, false, 512, 32, 128, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSE_LDS_NARROW);
+    hipFuncSetAttribute((const void *)k_walk_sort<uint32_t, true, 512, 32, 128, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void *)k_walk_sort<uint64_t, false, 1024, 16, 512, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_WIDE);
+    hipFuncSetAttribute((const void *)k_walk_sort<uint64_t, true, 1024, 16, 512, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
 }
 
-// sampling launch + bucket layout
+// sampling launch + bucket layout.  tally_rows: COUNT_WGS x n_tally words of scratch; tally_tot: n_tally words.
 void launch_provision(const uint32_t *codes, const uint32_t *restarts, const uint32_t *n_bases, const L2 *st2, const PartPlan &pl,
-                      uint32_t stride, uint32_t capacity, uint32_t *sample_hist, uint32_t *bucket_base, uint32_t *cursor1,
-                      uint32_t *cap_end, uint32_t *flags, hipStream_t s) {
+                      uint32_t stride, uint32_t *tally_rows, uint32_t *tally_tot, uint32_t *bucket_base, uint32_t *cursor1,
+                      uint32_t *cap_end, uint32_t *final_start, uint32_t *cursor2, uint32_t *cap2_end, uint32_t *flags, hipStream_t s) {
     const uint32_t n_sampled = (pl.n_chunks + stride - 1) / stride;
-    const uint32_t grid = n_sampled < 2048u ? n_sampled : 2048u;
-    hipMemsetAsync(sample_hist, 0, 512 * sizeof(uint32_t), s);
+    const uint32_t grid = n_sampled < COUNT_WGS ? n_sampled : COUNT_WGS;
+    const uint32_t n_tally = pl.n_tally;
+    const uint32_t tally_shift = n_tally > pl.B1 ? pl.fb_bits : pl.addr_bits - pl.b1;
+    hipMemsetAsync(tally_tot, 0, (size_t)n_tally * sizeof(uint32_t), s);
     if (pl.k <= 15)
-        hipLaunchKernelGGL((k_walk_sort<uint32_t, true>), dim3(grid), dim3(SC_T), SCATTER_LDS_NARROW, s, codes, restarts, n_bases, st2, pl, n_sampled,
-                           stride, (void *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, flags, (uint32_t *)nullptr, sample_hist,
-                           (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint64_t)0, getenv("PK_DBG") ? (uint32_t)atoi(getenv("PK_DBG")) : 0u);
+        hipLaunchKernelGGL((k_walk_sort<uint32_t, true, 512, 32, 128, 512>), dim3(grid), dim3(512), (size_t)n_tally * 4, s, codes, restarts, n_bases, st2,
+                           pl, n_sampled, stride, (void *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, flags, tally_shift, n_tally,
+                           tally_rows, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint64_t)0);
     else
-        hipLaunchKernelGGL((k_walk_sort<uint64_t, true>), dim3(grid), dim3(SC_T), SCATTER_LDS_WIDE, s, codes, restarts, n_bases, st2, pl, n_sampled,
-                           stride, (void *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, flags, (uint32_t *)nullptr, sample_hist,
-                           (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint64_t)0, getenv("PK_DBG") ? (uint32_t)atoi(getenv("PK_DBG")) : 0u);
-    hipLaunchKernelGGL(k_provision, dim3(1), dim3(512), 0, s, (const uint32_t *)sample_hist, pl, n_sampled, stride, capacity, bucket_base, cursor1,
-                       cap_end, flags);
+        hipLaunchKernelGGL((k_walk_sort<uint64_t, true, 1024, 16, 512, 1024>), dim3(grid), dim3(1024), (size_t)n_tally * 4, s, codes, restarts, n_bases,
+                           st2, pl, n_sampled, stride, (void *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, flags, tally_shift,
+                           n_tally, tally_rows, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint64_t)0);
+    hipLaunchKernelGGL(k_tally_sum, dim3((n_tally + 255u) / 256u, grid < 16u ? 1u : 16u), dim3(256), 0, s, (const uint32_t *)tally_rows, grid, n_tally,
+                       tally_tot);
+    hipLaunchKernelGGL(k_provision, dim3(1), dim3(1024), 0, s, (const uint32_t *)tally_tot, n_tally, pl, n_sampled, stride, bucket_base, cursor1, cap_end,
+                       final_start, cursor2, cap2_end, flags);
 }
 
 void launch_walk_sort(const uint32_t *codes, const uint32_t *restarts, const uint32_t *n_bases, const L2 *st2, const PartPlan &pl, void *out1,
-                      uint32_t *cursor1, const uint32_t *cap_end, uint32_t dump, uint32_t *flags, uint32_t *fine_rows,
-                      const uint32_t *bucket_base, uint32_t *bucket_end, uint32_t *compact_base, uint32_t *wg2_start,
-                      unsigned long long *side, unsigned long long *side_n, uint64_t side_cap, hipStream_t s) {
-    const size_t lds = fuse_lds(pl, fine_rows != nullptr);
+                      uint32_t *cursor1, const uint32_t *cap_end, uint32_t *flags, const uint32_t *bucket_base, uint32_t *bucket_end,
+                      uint32_t *compact_base, uint32_t *wg2_start, unsigned long long *side, unsigned long long *side_n, uint64_t side_cap,
+                      hipStream_t s) {
+    const uint32_t dump = (uint32_t)pl.capacity1;
     if (pl.k <= 15)
-        hipLaunchKernelGGL((k_walk_sort<uint32_t, false>), dim3(pl.n_wg0), dim3(SC_T), lds, s, codes, restarts, n_bases, st2, pl, pl.n_chunks, 1u, out1,
-                           cursor1, cap_end, dump, flags, fine_rows, (uint32_t *)nullptr, side, side_n, side_cap, getenv("PK_DBG") ? (uint32_t)atoi(getenv("PK_DBG")) : 0u);
+        hipLaunchKernelGGL((k_walk_sort<uint32_t, false, 512, 32, 128, 512>), dim3(pl.n_wg0), dim3(512), FUSE_LDS_NARROW, s, codes, restarts, n_bases, st2,
+                           pl, pl.n_chunks, 1u, out1, cursor1, cap_end, dump, flags, 0u, 0u, (uint32_t *)nullptr, side, side_n, side_cap);
     else
-        hipLaunchKernelGGL((k_walk_sort<uint64_t, false>), dim3(pl.n_wg0), dim3(SC_T), lds, s, codes, restarts, n_bases, st2, pl, pl.n_chunks, 1u, out1,
-                           cursor1, cap_end, dump, flags, fine_rows, (uint32_t *)nullptr, side, side_n, side_cap, 0u);
-    hipLaunchKernelGGL(k_level1_finish, dim3(1), dim3(512), 0, s, (const uint32_t *)cursor1, bucket_base, cap_end, pl, bucket_end, compact_base,
+        hipLaunchKernelGGL((k_walk_sort<uint64_t, false, 1024, 16, 512, 1024>), dim3(pl.n_wg0), dim3(1024), SCATTER_LDS_WIDE, s, codes, restarts, n_bases,
+                           st2, pl, pl.n_chunks, 1u, out1, cursor1, cap_end, dump, flags, 0u, 0u, (uint32_t *)nullptr, side, side_n, side_cap);
+    hipLaunchKernelGGL(k_level1_finish, dim3(1), dim3(1024), 0, s, (const uint32_t *)cursor1, bucket_base, cap_end, pl, bucket_end, compact_base,
                        wg2_start, (const uint32_t *)flags);
 }
 

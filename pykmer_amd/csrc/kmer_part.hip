@@ -6,13 +6,12 @@
 //
 //   kmer_pack.hip  k_squeeze     FASTA text -> packed valid bases (2-bit codes + restart bits), per-record tallies
 //   kmer_fuse.hip  k_walk_sort   packed bases -> canonical k-mers (in registers) -> LDS counting sort by the level-1
-//                                digit (top b1 address bits) -> coalesced run writes into provisioned buckets; for
-//                                k <= 15 it also tallies the size of every FINAL bucket (2^14 LDS counters per workgroup)
-//   K3 k_fine_sum / k_fine_scan  (k <= 15) final bucket starts + write cursors from those tallies
+//                                digit (top b1 address bits) -> coalesced run writes into provisioned buckets
 //      k_count2 / k_rows2_scan   (k = 17)  per-workgroup histogram of the level-2 digit (next b2 bits)
 //                    inside each level-1 bucket, per-bucket column scan -> offsets + final bucket starts
-//   K5 k_scatter2    second pass, 16-bit records (address inside the final bucket).  k <= 15: every tile
-//                    claims room for its runs from the cursors (atomicAdd), there is no counting pass
+//   K5 k_scatter2    second pass, 16-bit records (address inside the final bucket).  k <= 15: the final buckets were
+//                    laid out from the same sampled estimate as the level-1 ones; every tile claims room for its
+//                    runs from their cursors (atomicAdd), there is no counting pass
 //   K6 k_bucket_count one workgroup per final bucket of 2^16 addresses: the slice of the u8 table
 //                    lives in LDS as 16-bit counters, ds_add per record, clamp, slice written to HBM
 //                    (read back first when an earlier feed already wrote it)
@@ -30,41 +29,6 @@
 #include "part_common.h"
 
 namespace pk {
-
-// column sums of the per-workgroup final-bucket tallies: grid (n_fine / 256, row groups)
-__global__ __launch_bounds__(256) void k_fine_sum(const uint32_t *__restrict__ fine_rows, uint32_t n_rows, uint32_t n_fine,
-                                                  uint32_t *__restrict__ fine_tot, const uint32_t *__restrict__ flags) {
-    if (flags[0]) return;
-    const uint32_t col = blockIdx.x * 256u + threadIdx.x;
-    if (col >= n_fine) return;
-    const uint32_t per = (n_rows + gridDim.y - 1) / gridDim.y;
-    const uint32_t r_lo = blockIdx.y * per, r_hi = min(r_lo + per, n_rows);
-    uint32_t acc = 0;
-    for (uint32_t r = r_lo; r < r_hi; r++) acc += fine_rows[(uint64_t)r * n_fine + col];
-    if (acc) atomicAdd(&fine_tot[col], acc);
-}
-
-// exclusive scan of the final bucket sizes -> final_start[0 .. n_fine] and the write cursors level 2 claims from
-__global__ __launch_bounds__(1024) void k_fine_scan(const uint32_t *__restrict__ fine_tot, uint32_t n_fine,
-                                                    uint32_t *__restrict__ final_start, uint32_t *__restrict__ cursor,
-                                                    const uint32_t *__restrict__ flags) {
-    __shared__ uint32_t wsum[16];
-    if (flags[0]) return;
-    const uint32_t per = (n_fine + 1023u) / 1024u;                       // <= 16
-    const uint32_t lo = min(threadIdx.x * per, n_fine), hi = min(lo + per, n_fine);
-    uint32_t acc = 0;
-    for (uint32_t i = lo; i < hi; i++) acc += fine_tot[i];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t inc = acc;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    uint32_t a = inc - acc;
-    for (int i = 0; i < w; i++) a += wsum[i];
-    for (uint32_t i = lo; i < hi; i++) { final_start[i] = a; cursor[i] = a; a += fine_tot[i]; }
-    if (threadIdx.x == 1023) final_start[n_fine] = a;
-}
 
 // level-2 work split: bucket b is covered by workgroups wg2_start[b] .. wg2_start[b+1]-1, R2 records each
 __device__ __forceinline__ bool wg2_range(const uint32_t *__restrict__ wg2_start, const uint32_t *__restrict__ bucket_base,
@@ -131,13 +95,15 @@ __global__ __launch_bounds__(512) void k_rows2_scan(const uint32_t *__restrict__
     }
 }
 
-// CLAIM: no precomputed offsets; every tile claims room for its runs from the final buckets' cursors.  Where a
-// record lands inside its final bucket then depends on timing -- the bucket's contents as a multiset do not.
+// CLAIM: no precomputed offsets; every tile claims room for its runs from the final buckets' cursors, inside the
+// room k_provision gave each of them (cap_end; a bucket that outgrows it raises flags[0], see part_common.h).  Where
+// a record lands inside its final bucket then depends on timing -- the bucket's contents as a multiset do not.
 template <bool CLAIM>
 __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ wg2_start,
                                                    const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ bucket_end,
                                                    const uint32_t *__restrict__ rowoff, const uint32_t *__restrict__ final_start, PartPlan pl,
-                                                   void *__restrict__ out, uint32_t *__restrict__ cursor, const uint32_t *__restrict__ flags) {
+                                                   void *__restrict__ out, uint32_t *__restrict__ cursor, const uint32_t *__restrict__ cap_end,
+                                                   uint32_t dump, uint32_t *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     ScatterLds &L = *reinterpret_cast<ScatterLds *>(smem);
     uint32_t b, lo, hi;
@@ -181,7 +147,8 @@ __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ 
             for (int e = 0; e < 4; e++) { ok[j * 4 + e] = i + e >= v_lo && i + e < v_hi; r[j * 4 + e] = q[e]; }
         }
         if (win + TILE < hi) fetch(win + TILE, nxt);
-        scatter_tile<uint32_t, false>(L, r, ok, n_tile, shift, B, low_mask, true, out, settle, CLAIM ? cursor + (uint64_t)b * B : nullptr);
+        scatter_tile<uint32_t, false>(L, r, ok, n_tile, shift, B, low_mask, true, out, settle, CLAIM ? cursor + (uint64_t)b * B : nullptr,
+                                      CLAIM ? cap_end + (uint64_t)b * B : nullptr, dump, flags);
     }
 }
 
@@ -527,23 +494,28 @@ PartPlan make_part_plan(uint32_t k, uint64_t n_bytes) {
     uint64_t r2 = (n_bytes + 1023) / 1024;
     pl.R2 = r2 < (uint64_t)TILE ? (uint64_t)TILE : ((r2 + TILE - 1) / TILE) * TILE;
     pl.n_wg2_max = (uint32_t)(n_bytes / pl.R2) + pl.B1 + 1;
-    // level-1 bucket sizes are estimated from every 16th slot; small inputs are counted exactly
+    // bucket sizes are estimated from every 16th slot; small inputs are counted exactly
     pl.sample_stride = pl.n_chunks >= 1024u ? 16u : 1u;
-    // room for the level-1 buckets: the sampled estimate can reach the slot capacity (+1 per bucket from rounding
-    // up), each bucket gets 12.5 % + 4096 + alignment on top of it (k_provision)
-    const uint64_t est_max = (uint64_t)pl.n_chunks * TILE + pl.B1;
-    pl.capacity1 = est_max + est_max / 8 + (uint64_t)pl.B1 * 4100;
+    const uint64_t nfb = (uint64_t)pl.B1 * pl.B2;
+    pl.n_tally = (pl.b2 && nfb <= 16384 && k <= 15) ? (uint32_t)nfb : pl.B1;
+    // room for the buckets: the sampled estimate can reach the slot capacity (+1 per bucket from rounding up), each
+    // bucket gets 12.5 % + a constant + alignment on top of it (k_provision)
+    const uint64_t est1 = (uint64_t)pl.n_chunks * TILE + pl.B1, est2 = (uint64_t)pl.n_chunks * TILE + nfb;
+    pl.capacity1 = est1 + est1 / 8 + (uint64_t)pl.B1 * 4100;
+    pl.capacity2 = est2 + est2 / 8 + nfb * 2056;
     return pl;
 }
 
 size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace *lay) {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const uint64_t nfb = (uint64_t)pl.B1 * pl.B2;
+    const bool laid_out2 = pl.n_tally > pl.B1;               // final buckets provisioned from the estimate (k <= 15, two levels)
     size_t o = 0;
     lay->codes = o; o += up((size_t)pl.n_chunks * SLOT_CODE_WORDS * 4);
     lay->restarts = o; o += up((size_t)pl.n_chunks * SLOT_RST_WORDS * 4);
     lay->n_bases = o; o += up((size_t)pl.n_chunks * 4);
-    lay->sample_hist = o; o += up(512 * 4);
+    lay->tally_rows = o; o += up((size_t)COUNT_WGS * pl.n_tally * 4);
+    lay->tally_tot = o; o += up((size_t)pl.n_tally * 4);
     lay->bucket_base = o; o += up((size_t)(pl.B1 + 1) * 4);
     lay->bucket_end = o; o += up((size_t)(pl.B1 + 1) * 4);
     lay->compact_base = o; o += up((size_t)(pl.B1 + 1) * 4);
@@ -551,17 +523,15 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
     lay->cap_end = o; o += up((size_t)(pl.B1 + 1) * 4);
     lay->wg2_start = o; o += up((size_t)(pl.B1 + 1) * 4);
     lay->final_start = o; o += up((size_t)(nfb + 1) * 4);
+    lay->cursor2 = o; o += up((size_t)(nfb + 1) * 4);
+    lay->cap2_end = o; o += up((size_t)(nfb + 1) * 4);
     lay->out1 = o; o += up((size_t)(pl.capacity1 + TILE + 64) * (pl.b2 ? 4 : 2));      // buckets + the dump area
     lay->hist2 = o; o += up((size_t)pl.n_wg2_max * pl.B2 * 4);
     lay->rowoff2 = o; o += up((size_t)pl.n_wg2_max * pl.B2 * 4);
-    lay->out2 = o; o += up(pl.b2 ? (size_t)(n_bytes + 64) * 2 : 256);
+    lay->out2 = o; o += up(!pl.b2 ? 256 : laid_out2 ? (size_t)(pl.capacity2 + TILE + 64) * 2 : (size_t)(n_bytes + 64) * 2);
     lay->side_cap = n_bytes + 16;                          // every side entry stands for >= 1 k-mer
     lay->side = o; o += up((size_t)lay->side_cap * 8);
     lay->side_n = o; o += 256;                             // side-list length (u64), then the flags word
-    const bool fine = pl.b2 && nfb <= 16384 && pl.k <= 15;             // level 2 without a counting pass (see k_walk_sort)
-    lay->fine_rows = o; o += fine ? up((size_t)pl.n_wg0 * nfb * 4) : 0;
-    lay->fine_tot = o; o += fine ? up((size_t)nfb * 4) : 0;
-    lay->cursor = o; o += fine ? up((size_t)nfb * 4) : 0;
     lay->bucket_hist = o; o += up((size_t)nfb * 2 * 256 * 4);              // up to 2 workgroups per bucket
     return o;
 }
@@ -582,39 +552,37 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
                        unsigned long long *hist) {
     const uint32_t *codes = (const uint32_t *)(ws + lay.codes), *restarts = (const uint32_t *)(ws + lay.restarts);
     const uint32_t *n_bases = (const uint32_t *)(ws + lay.n_bases);
-    uint32_t *sample_hist = (uint32_t *)(ws + lay.sample_hist), *bucket_base = (uint32_t *)(ws + lay.bucket_base);
-    uint32_t *bucket_end = (uint32_t *)(ws + lay.bucket_end), *compact_base = (uint32_t *)(ws + lay.compact_base);
-    uint32_t *cursor1 = (uint32_t *)(ws + lay.cursor1), *cap_end = (uint32_t *)(ws + lay.cap_end), *wg2_start = (uint32_t *)(ws + lay.wg2_start);
-    uint32_t *final_start = (uint32_t *)(ws + lay.final_start), *hist2 = (uint32_t *)(ws + lay.hist2), *rowoff2 = (uint32_t *)(ws + lay.rowoff2);
+    uint32_t *tally_rows = (uint32_t *)(ws + lay.tally_rows), *tally_tot = (uint32_t *)(ws + lay.tally_tot);
+    uint32_t *bucket_base = (uint32_t *)(ws + lay.bucket_base), *bucket_end = (uint32_t *)(ws + lay.bucket_end);
+    uint32_t *compact_base = (uint32_t *)(ws + lay.compact_base), *cursor1 = (uint32_t *)(ws + lay.cursor1), *cap_end = (uint32_t *)(ws + lay.cap_end);
+    uint32_t *wg2_start = (uint32_t *)(ws + lay.wg2_start), *final_start = (uint32_t *)(ws + lay.final_start);
+    uint32_t *cursor2 = (uint32_t *)(ws + lay.cursor2), *cap2_end = (uint32_t *)(ws + lay.cap2_end);
+    uint32_t *hist2 = (uint32_t *)(ws + lay.hist2), *rowoff2 = (uint32_t *)(ws + lay.rowoff2);
     void *out1 = ws + lay.out1, *out2 = ws + lay.out2;
     unsigned long long *side = (unsigned long long *)(ws + lay.side), *side_n = (unsigned long long *)(ws + lay.side_n);
     uint32_t *flags = (uint32_t *)(side_n + 1);
     const uint32_t nfb = pl.B1 * pl.B2;
-    const bool fine = pl.b2 && nfb <= 16384 && pl.k <= 15;
+    const bool laid_out2 = pl.n_tally > pl.B1;
     if (hipMemsetAsync(side_n, 0, 16, s) != hipSuccess) return -2;   // side-list length + flags
-    launch_provision(codes, restarts, n_bases, st2, pl, stride, (uint32_t)pl.capacity1, sample_hist, bucket_base, cursor1, cap_end, flags, s);
-    uint32_t *fine_rows = (uint32_t *)(ws + lay.fine_rows), *fine_tot = (uint32_t *)(ws + lay.fine_tot), *cursor = (uint32_t *)(ws + lay.cursor);
+    launch_provision(codes, restarts, n_bases, st2, pl, stride, tally_rows, tally_tot, bucket_base, cursor1, cap_end, final_start, cursor2, cap2_end,
+                     flags, s);
     if (ev_sort_begin) hipEventRecord(ev_sort_begin, s);
-    launch_walk_sort(codes, restarts, n_bases, st2, pl, out1, cursor1, cap_end, (uint32_t)pl.capacity1, flags, fine ? fine_rows : nullptr,
-                     bucket_base, bucket_end, compact_base, wg2_start, side, side_n, lay.side_cap, s);
+    launch_walk_sort(codes, restarts, n_bases, st2, pl, out1, cursor1, cap_end, flags, bucket_base, bucket_end, compact_base, wg2_start, side, side_n,
+                     lay.side_cap, s);
     if (ev_sort_end) hipEventRecord(ev_sort_end, s);
     const uint16_t *final_recs = (const uint16_t *)out1;
     const uint32_t *k6_start = bucket_base, *k6_end = bucket_end;        // b2 == 0: the level-1 buckets are the final ones
-    if (fine) {
-        if (hipMemsetAsync(fine_tot, 0, (size_t)nfb * 4, s) != hipSuccess) return -2;
-        const uint32_t row_groups = pl.n_wg0 < 16u ? 1u : 16u;
-        hipLaunchKernelGGL(k_fine_sum, dim3((nfb + 255u) / 256u, row_groups), dim3(256), 0, s, (const uint32_t *)fine_rows, pl.n_wg0, nfb, fine_tot,
-                           (const uint32_t *)flags);
-        hipLaunchKernelGGL(k_fine_scan, dim3(1), dim3(1024), 0, s, (const uint32_t *)fine_tot, nfb, final_start, cursor, (const uint32_t *)flags);
+    if (laid_out2) {
         hipLaunchKernelGGL(k_scatter2<true>, dim3(pl.n_wg2_max), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
-                           bucket_base, bucket_end, (const uint32_t *)nullptr, final_start, pl, out2, cursor, (const uint32_t *)flags);
-        final_recs = (const uint16_t *)out2; k6_start = final_start; k6_end = nullptr;
+                           bucket_base, bucket_end, (const uint32_t *)nullptr, final_start, pl, out2, cursor2, (const uint32_t *)cap2_end,
+                           (uint32_t)pl.capacity2, flags);
+        final_recs = (const uint16_t *)out2; k6_start = final_start; k6_end = cursor2;   // a final bucket ends where its cursor stopped
     } else if (pl.b2) {
         hipLaunchKernelGGL(k_count2, dim3(pl.n_wg2_max), dim3(WG), 0, s, (const uint32_t *)out1, wg2_start, bucket_base, bucket_end, pl, hist2,
                            (const uint32_t *)flags);
         hipLaunchKernelGGL(k_rows2_scan, dim3(pl.B1), dim3(512), 0, s, hist2, rowoff2, wg2_start, compact_base, pl, final_start, (const uint32_t *)flags);
         hipLaunchKernelGGL(k_scatter2<false>, dim3(pl.n_wg2_max), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
-                           bucket_base, bucket_end, rowoff2, final_start, pl, out2, (uint32_t *)nullptr, (const uint32_t *)flags);
+                           bucket_base, bucket_end, rowoff2, final_start, pl, out2, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, flags);
         final_recs = (const uint16_t *)out2; k6_start = final_start; k6_end = nullptr;
     }
     if (ev_part_end) hipEventRecord(ev_part_end, s);

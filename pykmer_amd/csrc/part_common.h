@@ -22,14 +22,16 @@ constexpr int TILE = SC_T * SC_PER;  // 16384 records per tile = one FASTA chunk
 // which is appended to a global side list when the workgroup finishes (or the table half fills).
 // k_apply_side folds the side list into the finished u8 table with saturating CAS adds -- a few
 // thousand entries instead of 10^7..10^8 records.
-constexpr uint32_t HOT_SLOTS = 1024;     // per-workgroup LDS hash slots
 constexpr uint32_t HOT_PROBES = 16;
 constexpr uint32_t SIDE_CNT_BITS = 28;   // side entry = (addr << 28) | count
 
+template <uint32_t SLOTS>               // per-workgroup LDS hash slots (a power of two)
 struct HotTable {
-    unsigned long long key[HOT_SLOTS];   // addr + 1, 0 = empty
-    uint32_t val[HOT_SLOTS];
+    static constexpr uint32_t HOT_SLOTS = SLOTS;
+    unsigned long long key[SLOTS];       // addr + 1, 0 = empty
+    uint32_t val[SLOTS];
     uint32_t used, n_flush;
+    unsigned long long flush_base;
 };
 
 __device__ __forceinline__ void side_append_one(unsigned long long *side, unsigned long long *side_n, uint64_t side_cap,
@@ -38,8 +40,10 @@ __device__ __forceinline__ void side_append_one(unsigned long long *side, unsign
     if (i < side_cap) side[i] = ((unsigned long long)addr << SIDE_CNT_BITS) | cnt;
 }
 
-__device__ __forceinline__ void hot_insert(HotTable &H, uint64_t addr, uint32_t cnt, unsigned long long *side,
+template <uint32_t SLOTS>
+__device__ __forceinline__ void hot_insert(HotTable<SLOTS> &H, uint64_t addr, uint32_t cnt, unsigned long long *side,
                                            unsigned long long *side_n, uint64_t side_cap) {
+    constexpr uint32_t HOT_SLOTS = SLOTS;
     const unsigned long long key = addr + 1ull;
     uint32_t h = (uint32_t)((addr * 0x9E3779B97F4A7C15ull) >> 40) & (HOT_SLOTS - 1u);
 #pragma unroll 1                                               // rare path, inlined sixteen times into the walk loop: keep it small
@@ -55,27 +59,10 @@ __device__ __forceinline__ void hot_insert(HotTable &H, uint64_t addr, uint32_t 
     side_append_one(side, side_n, side_cap, addr, cnt);          // table crowded: straight to the side list
 }
 
-// Whole wave (uniform call): every lane with n > 0 contributes (addr, n); lanes holding the same addr
-// are summed with ballot + readlane and inserted once.  Deliberately not inlined: it runs a few times
-// per piece at most and would otherwise be replicated through the unrolled walk loop.
-__device__ __noinline__ void hot_insert_wave(HotTable *H, unsigned long long addr, uint32_t n, unsigned long long *side,
-                                             unsigned long long *side_n, uint64_t side_cap) {
-    const int lane = threadIdx.x & 63;
-    unsigned long long pending = __ballot(n != 0u);
-    while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const unsigned long long a = __shfl(addr, leader, 64);
-        const bool mine = n != 0u && addr == a;
-        const unsigned long long same = __ballot(mine);
-        uint32_t tot = mine ? n : 0u;
-        for (int d = 32; d; d >>= 1) tot += __shfl_xor(tot, d, 64);
-        if (lane == leader) hot_insert(*H, a, tot, side, side_n, side_cap);
-        pending &= ~same;
-    }
-}
-
 // all threads of the workgroup; appends every occupied slot to the side list and clears the table
-__device__ __forceinline__ void hot_flush(HotTable &H, unsigned long long *side, unsigned long long *side_n, uint64_t side_cap) {
+template <uint32_t SLOTS>
+__device__ __forceinline__ void hot_flush(HotTable<SLOTS> &H, unsigned long long *side, unsigned long long *side_n, uint64_t side_cap) {
+    constexpr uint32_t HOT_SLOTS = SLOTS;
     __syncthreads();
     if (threadIdx.x == 0) H.n_flush = 0;
     __syncthreads();
@@ -83,9 +70,9 @@ __device__ __forceinline__ void hot_flush(HotTable &H, unsigned long long *side,
     for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += blockDim.x) mine += H.key[i] != 0ull;
     uint32_t at = mine ? atomicAdd(&H.n_flush, mine) : 0u;
     __syncthreads();
-    __shared__ unsigned long long base64;
-    if (threadIdx.x == 0) base64 = H.n_flush ? atomicAdd(side_n, (unsigned long long)H.n_flush) : 0ull;
+    if (threadIdx.x == 0) H.flush_base = H.n_flush ? atomicAdd(side_n, (unsigned long long)H.n_flush) : 0ull;
     __syncthreads();
+    const unsigned long long base64 = H.flush_base;
     for (uint32_t i = threadIdx.x; i < HOT_SLOTS; i += blockDim.x) {
         if (H.key[i] != 0ull) {
             unsigned long long dst = base64 + at++;
@@ -102,13 +89,15 @@ __device__ __forceinline__ void hot_flush(HotTable &H, unsigned long long *side,
 // One tile = up to 16384 records: rank within digit by LDS atomic, exclusive scan of the digit
 // counts, records + digits parked in LDS in sorted order, then written as coalesced runs at
 // run[d] (this workgroup's running output offset for digit d).
-struct ScatterLds {
-    uint32_t hist[512], off[512], run[512], gbase[512];
+template <int NB>                  // NB = most destinations (digits) a tile is sorted into
+struct ScatterLdsT {
+    uint32_t hist[NB], off[NB], run[NB], gbase[NB];
     uint32_t wsum[SC_T / 64];
     uint32_t total, pad_[3];       // records of the tile being sorted
     uint32_t rec[TILE];
     uint16_t dig[TILE];            // only when the digit does not fit beside the record (k = 17, level 1)
 };
+typedef ScatterLdsT<512> ScatterLds;
 constexpr size_t SCATTER_LDS_NARROW = offsetof(ScatterLds, dig);   // 72 KiB: two workgroups per CU
 constexpr size_t SCATTER_LDS_WIDE = sizeof(ScatterLds);            // 104 KiB
 
@@ -127,14 +116,16 @@ constexpr size_t SCATTER_LDS_WIDE = sizeof(ScatterLds);            // 104 KiB
 // of the next tile -- also waits for the stores to be acknowledged by HBM, a full round trip of ~8 us per
 // tile with nothing else in flight.  Waiting here costs nothing (the loads were issued a whole sort ago)
 // and leaves the stores in flight through the next tile's ranking and parking.
-template <typename RIN, bool WIDE, class Settle>
-__device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PER], const bool (&ok)[SC_PER], uint32_t n_tile,
+// NT threads sort PER records each (NT * PER = TILE).
+template <typename RIN, bool WIDE, int NT = SC_T, int PER = SC_PER, int NB = 512, class Settle>
+__device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[PER], const bool (&ok)[PER], uint32_t n_tile,
                                              uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out,
                                              Settle &&settle, uint32_t *claim = nullptr, const uint32_t *__restrict__ cap_end = nullptr,
                                              uint32_t dump = 0, uint32_t *overflow = nullptr) {
-    uint32_t dr[SC_PER];                                   // digit (9 bits) | rank inside the tile << 9
+    static_assert(NT * PER == TILE, "tile shape");
+    uint32_t dr[PER];                                   // digit (9 bits) | rank inside the tile << 9
 #pragma unroll
-    for (int j = 0; j < SC_PER; j++) {
+    for (int j = 0; j < PER; j++) {
         dr[j] = 0;
         if (ok[j]) {
             const uint32_t dg = (uint32_t)((uint64_t)r[j] >> shift) & (B - 1u);
@@ -142,7 +133,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
         }
     }
     __syncthreads();
-    // exclusive scan of hist[0..B) by the first B threads (B <= 512 <= SC_T)
+    // exclusive scan of hist[0..B) by the first B threads (B <= NB <= NT)
     uint32_t my_off = 0, claimed = 0;
     {
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -172,7 +163,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
     __syncthreads();
     if (n_tile == ~0u) n_tile = L.total;
 #pragma unroll
-    for (int j = 0; j < SC_PER; j++)
+    for (int j = 0; j < PER; j++)
         if (ok[j]) {
             const uint32_t dg = dr[j] & 511u;
             const uint32_t p = L.off[dg] + (dr[j] >> 9);
@@ -187,8 +178,8 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
         // dword when they fall in the same run and the destination is even (the common case)
         uint16_t *o16 = reinterpret_cast<uint16_t *>(out);
 #pragma unroll
-        for (int j = 0; j < SC_PER / 2; j++) {
-            const uint32_t p = 2u * (threadIdx.x + j * SC_T);
+        for (int j = 0; j < PER / 2; j++) {
+            const uint32_t p = 2u * (threadIdx.x + j * NT);
             if (p < n_tile) {
                 const uint32_t r0 = L.rec[p], r1 = p + 1 < n_tile ? L.rec[p + 1] : 0u;
                 const uint32_t d0 = WIDE ? L.dig[p] : (r0 >> shift) & (B - 1u);
@@ -206,8 +197,8 @@ __device__ __forceinline__ void scatter_tile(ScatterLds &L, const RIN (&r)[SC_PE
         // 32-bit records: neighbours in sorted order leave as one 8-byte store when they share a run
         uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
 #pragma unroll
-        for (int j = 0; j < SC_PER / 2; j++) {
-            const uint32_t p = 2u * (threadIdx.x + j * SC_T);
+        for (int j = 0; j < PER / 2; j++) {
+            const uint32_t p = 2u * (threadIdx.x + j * NT);
             if (p < n_tile) {
                 const uint32_t r0 = L.rec[p], r1 = p + 1 < n_tile ? L.rec[p + 1] : 0u;
                 const uint32_t d0 = WIDE ? L.dig[p] : (r0 >> shift) & (B - 1u);

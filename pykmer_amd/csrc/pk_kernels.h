@@ -48,12 +48,16 @@ struct PartPlan {
     uint32_t n_wg0, G;       // persistent workgroups of the squeeze / sort kernels and chunks per workgroup
     uint64_t R2;             // records per level-2 workgroup
     uint32_t n_wg2_max;      // upper bound on level-2 workgroups
-    uint32_t sample_stride;  // every how-manieth slot is tallied to size the level-1 buckets (1 = all: exact)
+    uint32_t sample_stride;  // every how-manieth slot is tallied to size the buckets (1 = all: exact)
+    uint32_t n_tally;        // what the sampling launch tallies: B1 * B2 final buckets (both levels are then laid out from
+                             // the estimate), or just the B1 level-1 buckets (one level, or too many final buckets: k = 17)
     uint64_t capacity1;      // record slots for all level-1 buckets together (the dump area starts there)
+    uint64_t capacity2;      // the same for the final buckets, where they are laid out from the estimate
 };
+constexpr uint32_t COUNT_WGS = 256;   // workgroups (= tally rows) of the sampling launch
 struct PartWorkspace {       // byte offsets into one device allocation
-    size_t codes, restarts, n_bases, sample_hist, bucket_base, bucket_end, compact_base, cursor1, cap_end, wg2_start, final_start, out1, hist2,
-        rowoff2, out2, side, side_n, bucket_hist, fine_rows, fine_tot, cursor;
+    size_t codes, restarts, n_bases, tally_rows, tally_tot, bucket_base, bucket_end, compact_base, cursor1, cap_end, wg2_start, final_start, cursor2,
+        cap2_end, out1, hist2, rowoff2, out2, side, side_n, bucket_hist;
     uint64_t side_cap;
 };
 PartPlan make_part_plan(uint32_t k, uint64_t n_bytes);
@@ -61,12 +65,12 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
 void part_set_attributes();
 void fuse_set_attributes();
 void launch_provision(const uint32_t *codes, const uint32_t *restarts, const uint32_t *n_bases, const L2 *st2, const PartPlan &pl,
-                      uint32_t stride, uint32_t capacity, uint32_t *sample_hist, uint32_t *bucket_base, uint32_t *cursor1,
-                      uint32_t *cap_end, uint32_t *flags, hipStream_t s);
+                      uint32_t stride, uint32_t *tally_rows, uint32_t *tally_tot, uint32_t *bucket_base, uint32_t *cursor1,
+                      uint32_t *cap_end, uint32_t *final_start, uint32_t *cursor2, uint32_t *cap2_end, uint32_t *flags, hipStream_t s);
 void launch_walk_sort(const uint32_t *codes, const uint32_t *restarts, const uint32_t *n_bases, const L2 *st2, const PartPlan &pl, void *out1,
-                      uint32_t *cursor1, const uint32_t *cap_end, uint32_t dump, uint32_t *flags, uint32_t *fine_rows,
-                      const uint32_t *bucket_base, uint32_t *bucket_end, uint32_t *compact_base, uint32_t *wg2_start,
-                      unsigned long long *side, unsigned long long *side_n, uint64_t side_cap, hipStream_t s);
+                      uint32_t *cursor1, const uint32_t *cap_end, uint32_t *flags, const uint32_t *bucket_base, uint32_t *bucket_end,
+                      uint32_t *compact_base, uint32_t *wg2_start, unsigned long long *side, unsigned long long *side_n, uint64_t side_cap,
+                      hipStream_t s);
 int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint32_t stride, uint8_t *ws, const PartWorkspace &lay, uint8_t *table8,
                        hipStream_t s, hipEvent_t ev_sort_begin, hipEvent_t ev_sort_end, hipEvent_t ev_part_end, bool fresh,
                        unsigned long long *hist);
