@@ -92,50 +92,71 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
     // items: this workgroup's slots (persistent over a contiguous range), or every stride-th slot when sampling
     const uint32_t i_lo = COUNT ? blockIdx.x : blockIdx.x * pl.G, i_hi = COUNT ? n_items : min(i_lo + pl.G, n_items);
     const uint32_t i_step = COUNT ? gridDim.x : 1u;
-    auto no_settle = []() {};
-    for (uint32_t it = i_lo; it < i_hi; it += i_step) {
-        const uint32_t c = COUNT ? it * stride : it;
-        const uint32_t nb = n_bases[c];                                   // uniform
-        if (nb == 0) continue;
-        // ---- this thread's PER bases (NW code dwords), the 16 before them, and the restart bits of all of them
+    // One slot's worth of input per thread: the base count, the thread's NW code dwords and the one before them, the two
+    // restart dwords, the chunk's start state.  All of it is requested one tile AHEAD (before the current tile is
+    // assembled and sorted) and taken delivery of right before the current tile's runs are stored (settle): on this
+    // ISA loads and stores share one in-order counter, so a load waited for after the stores would also wait for the
+    // stores to be acknowledged by HBM -- a round trip per tile with nothing else in flight.  Addresses are in range
+    // for every thread whatever the slot holds; what lies past the base count is masked later.
+    struct Fetched { uint32_t nb, prev0, r_here, r_before, st_flags, st_bits, cur[NW]; };
+    auto fetch = [&](uint32_t c, Fetched &f) {
         const uint32_t *cw = codes + (uint64_t)c * SLOT_CODE_WORDS;
         const uint32_t *rw = restarts + (uint64_t)c * SLOT_RST_WORDS;
+        f.nb = n_bases[c];
+#pragma unroll
+        for (int w = 0; w < NW; w++) f.cur[w] = cw[NW * t + w];
+        f.prev0 = cw[t ? NW * t - 1 : 0];
+        const uint32_t ri = NW == 2 ? t : (t >> 1);
+        f.r_here = rw[ri];
+        f.r_before = rw[ri ? ri - 1 : 0];
+        f.st_flags = chunk_l2_state[c].flags;
+        f.st_bits = chunk_l2_state[c].bits;
+    };
+    Fetched nxt;
+    auto settle = [&]() {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0); lgkmcnt / expcnt untouched
+        asm volatile("" : "+v"(nxt.nb), "+v"(nxt.prev0), "+v"(nxt.r_here), "+v"(nxt.r_before), "+v"(nxt.st_flags), "+v"(nxt.st_bits));
+#pragma unroll
+        for (int w = 0; w < NW; w++) asm volatile("" : "+v"(nxt.cur[w]));
+    };
+    auto item_chunk = [&](uint32_t it) { return COUNT ? it * stride : it; };
+    if (i_lo < i_hi) fetch(item_chunk(i_lo), nxt);
+    settle();
+    for (uint32_t it = i_lo; it < i_hi; it += i_step) {
+        const Fetched me = nxt;
+        if (it + i_step < i_hi) fetch(item_chunk(it + i_step), nxt);
+        const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)me.nb);           // uniform
+        if (nb == 0) { settle(); continue; }
+        // ---- this thread's PER bases (NW code dwords), the 16 before them, and the restart bits of all of them
         const bool live = (uint32_t)PER * t < nb;
-        uint32_t cur[NW], prev0 = 0, rbits[NW];                           // rbits[w]: restart bits of the 16 bases before word w (low half) and of word w (high half)
+        uint32_t cur[NW], prev0 = me.prev0, rbits[NW];                    // rbits[w]: restart bits of the 16 bases before word w (low half) and of word w (high half)
 #pragma unroll
-        for (int w = 0; w < NW; w++) { cur[w] = 0; rbits[w] = 0; }
-        if (live) {
-#pragma unroll
-            for (int w = 0; w < NW; w++) cur[w] = cw[NW * t + w];
-            if (NW == 2) {
-                const uint32_t r_here = rw[t], r_before = t ? rw[t - 1] : 0u;
-                rbits[0] = (r_here << 16) | (r_before >> 16);
-                rbits[NW - 1] = r_here;
-            } else {
-                const uint32_t r_here = rw[t >> 1], r_before = t > 1 ? rw[(t >> 1) - 1] : 0u;
-                rbits[0] = (t & 1u) ? r_here : ((r_here << 16) | (r_before >> 16));
-            }
-            if (t == 0) {
-                // the k-1 bases in front of the slot: the chunk's start state (newest base lowest) in stream order
-                const L2 st = chunk_l2_state[c];
-                const uint32_t len = l2_len(st);
-                prev0 = revpairs32(st.bits);
-                rbits[0] &= 0xffff0000u;
-                if (len < km1) rbits[0] |= 1u << (16u - len);             // nothing older than those `len` bases may be used
-            } else {
-                prev0 = cw[NW * t - 1];
-            }
+        for (int w = 0; w < NW; w++) { cur[w] = live ? me.cur[w] : 0u; rbits[w] = 0; }
+        if (NW == 2) {
+            rbits[0] = (me.r_here << 16) | (me.r_before >> 16);
+            rbits[NW - 1] = me.r_here;
+        } else {
+            rbits[0] = (t & 1u) ? me.r_here : ((me.r_here << 16) | (me.r_before >> 16));
+        }
+        if (t == 0) {
+            // the k-1 bases in front of the slot: the chunk's start state (newest base lowest) in stream order
+            const uint32_t len = (me.st_flags >> 8) & 0xffu;              // l2_len
+            prev0 = revpairs32(me.st_bits);
+            rbits[0] &= 0xffff0000u;
+            if (len < km1) rbits[0] |= 1u << (16u - len);                 // nothing older than those `len` bases may be used
         }
         const uint32_t n_mine = live ? min((uint32_t)PER, nb - (uint32_t)PER * t) : 0u;
 
         KT r[PER];
-        bool ok[PER];
-        // The lane remembers its last three distinct k-mers.  A k-mer is emitted the first time it is seen;
-        // seeing it again while remembered (tandem repeats of period 1-3: the contended buckets) only
-        // bumps a counter, which goes to the workgroup's LDS table when the entry is evicted or the
-        // thread's bases end.  Either route counts each k-mer exactly once.  a1, a2, a3 are pairwise
-        // distinct (an entry is only ever inserted on a miss; the initial ~0 is no k-mer), so at most one
-        // compare hits.  The three counters share one register: n1 | n2 << 8 | n3 << 16.
+        uint32_t okm = 0;                                                 // bit j: r[j] is a record
+        // The lane remembers up to three distinct k-mers it has met.  A k-mer is emitted the first time it is seen;
+        // seeing it again while remembered (tandem repeats of period 1-3: the contended buckets) only bumps a
+        // counter, which goes to the workgroup's LDS table when the thread's bases end.  Either route counts each
+        // k-mer exactly once.  A new k-mer enters at a1 and pushes the others down; an entry that has collected
+        // repeats is never pushed out -- once the oldest one has, the cache stays as it is (what comes after a
+        // tandem run is emitted without being remembered).  a1, a2, a3 are pairwise distinct (an entry is only ever
+        // inserted on a miss; the initial ~0 is no k-mer), so at most one compare hits.  The three counters share
+        // one register: n1 | n2 << 8 | n3 << 16.
         KT a1 = ~(KT)0, a2 = ~(KT)0, a3 = ~(KT)0;
         uint32_t nn = 0;
 #pragma unroll
@@ -146,29 +167,31 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
             const uint32_t hasmask = ~(smear_up(rbits[w], km1) >> 16) & ((1u << cnt) - 1u);
             const uint32_t fprev = revpairs32(prev), fcur = revpairs32(cur[w]);
             const unsigned long long fwd64 = ((unsigned long long)fprev << 32) | fcur;      // first base highest
-            const unsigned long long rev64 = ~(((unsigned long long)cur[w] << 32) | prev);  // complemented, first base lowest
-            const uint32_t rev_sh0 = 2u * (17u - k);                                         // + 2j per base; < 64 for every odd k <= 17
+            // complemented, first base lowest, shifted once so that the window ending at base j starts at bit 2j
+            const unsigned long long rev64 = (~(((unsigned long long)cur[w] << 32) | prev)) >> (2u * (17u - k));
+            const uint32_t rlo = (uint32_t)rev64, rhi = (uint32_t)(rev64 >> 32);
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                KT f;
-                if (sizeof(KT) == 4) f = (KT)__builtin_amdgcn_alignbit(fprev, fcur, 2u * (15u - j)) & mask;
-                else f = (KT)(fwd64 >> (2u * (15u - j))) & mask;
-                const KT rv = (KT)(rev64 >> (rev_sh0 + 2u * j)) & mask;
+                KT f, rv;
+                if (sizeof(KT) == 4) {
+                    f = (KT)__builtin_amdgcn_alignbit(fprev, fcur, 2u * (15u - j)) & mask;
+                    rv = (KT)__builtin_amdgcn_alignbit(rhi, rlo, 2u * j) & mask;
+                } else {
+                    f = (KT)(fwd64 >> (2u * (15u - j))) & mask;
+                    rv = (KT)(rev64 >> (2u * j)) & mask;
+                }
                 const KT canon = f < rv ? f : rv;                                           // indexer.py:341
                 const bool has = (hasmask >> j) & 1u;
                 const bool e1 = canon == a1, e2 = canon == a2, e3 = canon == a3;
-                const bool h1 = has & e1, h2 = has & e2, h3 = has & e3;
                 const bool miss = has & !e1 & !e2 & !e3;
-                nn += h1 ? 1u : (h2 ? 0x100u : (h3 ? 0x10000u : 0u));
-                const uint32_t ev_n = miss ? (nn >> 16) : 0u;
-                const KT ev_a = a3;
-                a3 = miss ? a2 : a3;
-                a2 = miss ? a1 : a2;
-                a1 = miss ? canon : a1;
-                nn = miss ? ((nn << 8) & 0xffff00u) : nn;
+                nn += (has & e1) ? 1u : ((has & e2) ? 0x100u : ((has & e3) ? 0x10000u : 0u));
+                const bool push = miss & (nn < 0x10000u);                                   // the oldest entry holds no repeats: it may go
+                a3 = push ? a2 : a3;
+                a2 = push ? a1 : a2;
+                a1 = push ? canon : a1;
+                nn = push ? (nn << 8) : nn;
                 r[16 * w + j] = canon;
-                ok[16 * w + j] = miss;
-                if (!COUNT && ev_n != 0u) hot_insert(hot, (uint64_t)ev_a, ev_n, side, side_n, side_cap);   // rare: leaving a tandem run
+                okm |= miss ? (1u << (16 * w + j)) : 0u;
             }
         }
         // ---- hot keys leave the thread.  Tandem runs span many lanes: a lane whose predecessor (the bases before)
@@ -181,8 +204,8 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
                 if (prev_nn != 0u) {
 #pragma unroll
                     for (int j = 0; j < PER; j++) {
-                        if (ok[j] && (r[j] == p1 || r[j] == p2 || r[j] == p3)) {
-                            ok[j] = false;
+                        if (((okm >> j) & 1u) && (r[j] == p1 || r[j] == p2 || r[j] == p3)) {
+                            okm &= ~(1u << j);
                             if (!COUNT) hot_insert(hot, (uint64_t)r[j], 1u, side, side_n, side_cap);
                         }
                     }
@@ -197,10 +220,11 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
         if (COUNT) {
 #pragma unroll
             for (int j = 0; j < PER; j++)
-                if (ok[j]) atomicAdd(&tally[(uint32_t)((uint64_t)r[j] >> tally_shift)], 1u);
+                if ((okm >> j) & 1u) atomicAdd(&tally[(uint32_t)((uint64_t)r[j] >> tally_shift)], 1u);
+            settle();
             continue;
         }
-        scatter_tile<KT, WIDE, NT>(L, r, ok, ~0u, shift, B, low_mask, out16, out, no_settle, cursor1, cap_end, dump, flags);
+        scatter_tile<KT, WIDE, NT>(L, r, okm, ~0u, shift, B, low_mask, out16, out, settle, cursor1, cap_end, dump, flags);
         if (hot.used >= HS / 2) hot_flush(hot, side, side_n, side_cap);   // uniform: read after the barrier that ends the tile
     }
     if (COUNT) {

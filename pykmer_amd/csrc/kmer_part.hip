@@ -138,16 +138,16 @@ __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ 
         const uint32_t v_lo = max(lo, win), v_hi = min(hi, win + (uint32_t)TILE);
         const uint32_t n_tile = v_hi - v_lo;
         uint32_t r[SC_PER];
-        bool ok[SC_PER];
+        uint32_t okm = 0;
 #pragma unroll
         for (int j = 0; j < SC_PER / 4; j++) {
             const uint32_t i = win + (threadIdx.x + j * SC_T) * 4u;
             const uint32_t q[4] = {nxt[j].x, nxt[j].y, nxt[j].z, nxt[j].w};
 #pragma unroll
-            for (int e = 0; e < 4; e++) { ok[j * 4 + e] = i + e >= v_lo && i + e < v_hi; r[j * 4 + e] = q[e]; }
+            for (int e = 0; e < 4; e++) { okm |= (i + e >= v_lo && i + e < v_hi) ? (1u << (j * 4 + e)) : 0u; r[j * 4 + e] = q[e]; }
         }
         if (win + TILE < hi) fetch(win + TILE, nxt);
-        scatter_tile<uint32_t, false>(L, r, ok, n_tile, shift, B, low_mask, true, out, settle, CLAIM ? cursor + (uint64_t)b * B : nullptr,
+        scatter_tile<uint32_t, false>(L, r, okm, n_tile, shift, B, low_mask, true, out, settle, CLAIM ? cursor + (uint64_t)b * B : nullptr,
                                       CLAIM ? cap_end + (uint64_t)b * B : nullptr, dump, flags);
     }
 }

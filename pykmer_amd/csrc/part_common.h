@@ -116,9 +116,10 @@ constexpr size_t SCATTER_LDS_WIDE = sizeof(ScatterLds);            // 104 KiB
 // of the next tile -- also waits for the stores to be acknowledged by HBM, a full round trip of ~8 us per
 // tile with nothing else in flight.  Waiting here costs nothing (the loads were issued a whole sort ago)
 // and leaves the stores in flight through the next tile's ranking and parking.
-// NT threads sort PER records each (NT * PER = TILE).
+// NT threads sort PER records each (NT * PER = TILE); bit j of `okm` tells whether r[j] holds a record (one
+// register instead of PER lane masks: 32 booleans do not fit the scalar register file).
 template <typename RIN, bool WIDE, int NT = SC_T, int PER = SC_PER, int NB = 512, class Settle>
-__device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[PER], const bool (&ok)[PER], uint32_t n_tile,
+__device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[PER], uint32_t okm, uint32_t n_tile,
                                              uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out,
                                              Settle &&settle, uint32_t *claim = nullptr, const uint32_t *__restrict__ cap_end = nullptr,
                                              uint32_t dump = 0, uint32_t *overflow = nullptr) {
@@ -127,7 +128,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
 #pragma unroll
     for (int j = 0; j < PER; j++) {
         dr[j] = 0;
-        if (ok[j]) {
+        if ((okm >> j) & 1u) {
             const uint32_t dg = (uint32_t)((uint64_t)r[j] >> shift) & (B - 1u);
             dr[j] = dg | (atomicAdd(&L.hist[dg], 1u) << 9);
         }
@@ -164,7 +165,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     if (n_tile == ~0u) n_tile = L.total;
 #pragma unroll
     for (int j = 0; j < PER; j++)
-        if (ok[j]) {
+        if ((okm >> j) & 1u) {
             const uint32_t dg = dr[j] & 511u;
             const uint32_t p = L.off[dg] + (dr[j] >> 9);
             if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)dg; }
