@@ -245,8 +245,14 @@ __device__ __forceinline__ uint32_t piece_len(uint64_t chunk_base, uint64_t n_by
 // count is uniform (callers may use wave-wide ballots inside f); `active` is false past the lane's
 // last byte.  16 bytes are fetched per ds_read_b128 and shifted through four registers.
 template <class Fn>
+__device__ __forceinline__ void for_each_byte_of(const uint8_t *mine, uint32_t nb, Fn &&f);
+template <class Fn>
 __device__ __forceinline__ void for_each_byte(const uint8_t *lds, uint32_t nb, Fn &&f) {
-    const uint8_t *mine = lds + threadIdx.x * LDS_STRIDE;
+    for_each_byte_of(lds + threadIdx.x * LDS_STRIDE, nb, f);
+}
+// the same over a piece that starts at `mine` (16-byte aligned, 64 contiguous bytes)
+template <class Fn>
+__device__ __forceinline__ void for_each_byte_of(const uint8_t *mine, uint32_t nb, Fn &&f) {
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
 #pragma unroll 1
     for (uint32_t i = 0; i < (uint32_t)PIECE; i++) {

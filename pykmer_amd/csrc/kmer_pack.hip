@@ -67,8 +67,8 @@ __device__ __forceinline__ uint32_t movemask4(uint32_t flags80) {       // 0x80-
     return (flags80 * 0x00204081u) >> 28;
 }
 
-__device__ __forceinline__ void squeeze_clean(const uint8_t *lds, SeqWalker &wk, PieceBases &pb) {
-    const uint4 *mine = reinterpret_cast<const uint4 *>(lds + threadIdx.x * LDS_STRIDE);
+__device__ __forceinline__ void squeeze_clean(const uint8_t *piece, SeqWalker &wk, PieceBases &pb) {
+    const uint4 *mine = reinterpret_cast<const uint4 *>(piece);
     uint32_t tm[2] = {0, 0}, vm[2] = {0, 0}, cw[4] = {0, 0, 0, 0};     // terminators, valid bases, codes (byte i -> bits 2i)
 #pragma unroll
     for (int q = 0; q < PIECE / 16; q++) {
@@ -155,12 +155,45 @@ __device__ __forceinline__ void squeeze_clean(const uint8_t *lds, SeqWalker &wk,
     pb.n = live ? nv : 0u;
 }
 
+// ---- staging: the chunk's 16 KiB as a plain image in LDS (the lane's piece = 64 contiguous bytes; the 4-way bank
+// conflict on its four 16-byte reads is noise here).  Full chunks arrive by LDS-DMA (global_load_lds: no registers,
+// asynchronous -- the NEXT chunk's image is requested before the current one is squeezed and lands meanwhile); a chunk
+// that reaches the end of the stream goes through registers so that bytes past the end are never read and arrive as 0.
+__device__ __forceinline__ void stage_image_async(const uint8_t *__restrict__ fasta, uint64_t chunk_base, uint8_t *buf) {
+#pragma unroll
+    for (int i = 0; i < CHUNK / (WG * 16); i++) {
+        const uint32_t p = i * WG + threadIdx.x;                             // 16-byte piece of the chunk; one wave-instruction = 1 KiB
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fasta + chunk_base + (uint64_t)p * 16u),
+                                         (__attribute__((address_space(3))) void *)(buf + (p & ~63u) * 16u), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void stage_image_tail(const uint8_t *__restrict__ fasta, uint64_t chunk_base, uint64_t n_bytes, uint8_t *buf) {
+#pragma unroll
+    for (int i = 0; i < CHUNK / (WG * 16); i++) {
+        const uint32_t p = i * WG + threadIdx.x;
+        const uint64_t g = chunk_base + (uint64_t)p * 16u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g + 16u <= n_bytes) {
+            v = *reinterpret_cast<const uint4 *>(fasta + g);
+        } else if (g < n_bytes) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (uint32_t j = 0; j < (uint32_t)(n_bytes - g); j++) w[j >> 2] |= (uint32_t)fasta[g + j] << (8u * (j & 3u));
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        *reinterpret_cast<uint4 *>(buf + p * 16u) = v;
+    }
+}
+__device__ __forceinline__ void stage_image(const uint8_t *__restrict__ fasta, uint64_t chunk_base, uint64_t n_bytes, uint8_t *buf) {
+    if (chunk_base + CHUNK <= n_bytes) stage_image_async(fasta, chunk_base, buf);     // uniform
+    else stage_image_tail(fasta, chunk_base, n_bytes, buf);
+}
+
 __global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
                                                 const LaneState *__restrict__ lane_state, const L2 *__restrict__ chunk_l2_state,
                                                 uint32_t k, uint32_t n_chunks, uint32_t chunks_per_wg, uint32_t *__restrict__ codes,
                                                 uint32_t *__restrict__ restarts, uint32_t *__restrict__ n_bases,
                                                 DevRec *__restrict__ recs, uint64_t recs_cap, Carry *carry) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[WG * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t image[2][CHUNK];
     __shared__ __attribute__((aligned(16))) uint32_t slot_codes[SLOT_CODE_WORDS + 8];   // + slack: lds_or_bits touches up to 5 words
     __shared__ __attribute__((aligned(16))) uint32_t slot_rst[SLOT_RST_WORDS + 8];
     __shared__ uint32_t scan_sh[WG / 64];
@@ -172,24 +205,27 @@ __global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fast
     SeqWalker wk;
     wk.setup(k, recs, recs_cap, &racc);
     const uint32_t c_lo = blockIdx.x * chunks_per_wg, c_hi = min(c_lo + chunks_per_wg, n_chunks);
-    __syncthreads();
+    if (c_lo < c_hi) stage_image(fasta, (uint64_t)c_lo * CHUNK, n_bytes, image[0]);
     for (uint32_t c = c_lo; c < c_hi; c++) {
         const uint64_t base = (uint64_t)c * CHUNK;
-        recacc_retarget(racc, chunk_l2_state[c].rec, recs, recs_cap);    // published by the barrier below
-        stage_chunk(fasta, base, n_bytes, lds);
-        __syncthreads();
+        const uint8_t *buf = image[(c - c_lo) & 1u];
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's share of the image has landed ...
+        recacc_retarget(racc, chunk_l2_state[c].rec, recs, recs_cap);
+        __syncthreads();                                   // ... and so has everyone else's; the other image is free (its readers passed the last barrier)
+        if (c + 1 < c_hi) stage_image(fasta, base + CHUNK, n_bytes, image[(c - c_lo + 1) & 1u]);
         const uint32_t nb = piece_len(base, n_bytes);
         // exact parser state at this lane's first byte: chunk state . lane prefix (both from the structure pass)
         const LaneState lst = lane_state[(uint64_t)c * WG + threadIdx.x];
         const L2 st2 = l2_compose(chunk_l2_state[c], lane_state_l2(lst), km1);
         const uint32_t ls_in = lane_state_ls(lst);
         wk.begin(ls_in, st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
+        const uint8_t *piece = buf + threadIdx.x * PIECE;
         PieceBases pb;
         pb.clear();
         if (__all(!lane_state_dirty(lst) && ls_in != LS_HEADER && st2.p_tail == 0)) {     // the common case: plain sequence lines
-            squeeze_clean(lds, wk, pb);
+            squeeze_clean(piece, wk, pb);
         } else {
-            for_each_byte(lds, nb, [&](uint32_t i, uint32_t ch, bool act) {
+            for_each_byte_of(piece, nb, [&](uint32_t i, uint32_t ch, bool act) {
                 uint32_t code;
                 bool rst;
                 const bool take = wk.step(i, ch, act, code, rst);
@@ -215,11 +251,7 @@ __global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fast
             gr[threadIdx.x] = reinterpret_cast<uint4 *>(slot_rst)[threadIdx.x];
             reinterpret_cast<uint4 *>(slot_rst)[threadIdx.x] = make_uint4(0, 0, 0, 0);
         }
-        if (threadIdx.x == 0) {
-            n_bases[c] = total;
-            slot_codes[SLOT_CODE_WORDS] = 0; slot_rst[SLOT_RST_WORDS] = 0;               // the slack words a full slot may have touched
-        }
-        __syncthreads();                                   // pieces consumed, slot cleared; LDS may be restaged
+        if (threadIdx.x == 0) n_bases[c] = total;
     }
     wk.finish();
     recacc_finish(racc, recs, recs_cap, carry);
