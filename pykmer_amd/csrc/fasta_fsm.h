@@ -232,6 +232,12 @@ __device__ __forceinline__ void stage_chunk(const uint8_t *__restrict__ fasta, u
         *reinterpret_cast<uint4 *>(lds + (bo / PIECE) * LDS_STRIDE + (bo % PIECE)) = v;
     }
 }
+__device__ __forceinline__ uint32_t piece_len_of(uint32_t piece, uint64_t chunk_base, uint64_t n_bytes) {
+    uint64_t start = chunk_base + (uint64_t)piece * PIECE;
+    if (start >= n_bytes) return 0;
+    uint64_t left = n_bytes - start;
+    return left < (uint64_t)PIECE ? (uint32_t)left : (uint32_t)PIECE;
+}
 __device__ __forceinline__ uint32_t piece_len(uint64_t chunk_base, uint64_t n_bytes) {
     uint64_t start = chunk_base + (uint64_t)threadIdx.x * PIECE;
     if (start >= n_bytes) return 0;
@@ -271,10 +277,10 @@ __device__ __forceinline__ void for_each_byte_of(const uint8_t *mine, uint32_t n
 // the clean-piece loops rely on "byte > 13 means sequence character"): such pieces need
 // the full state machine; pieces that are not dirty and do not start inside a header line are
 // "clean" and take the short paths below and in kmer_walk.h.
-__device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb, bool &dirty) {
+__device__ __forceinline__ L1 piece_l1_at(const uint8_t *mine, uint32_t nb, bool &dirty) {   // mine: the piece's 64 bytes
     uint32_t st = LS_START;
     bool ht = false, d = false;
-    for_each_byte(lds, nb, [&](uint32_t, uint32_t c, bool act) {
+    for_each_byte_of(mine, nb, [&](uint32_t, uint32_t c, bool act) {
         const bool ws = is_ws(c), gt = c == '>';
         const bool term = act && is_term(c);
         const bool opens = act && st == LS_START && !ws;
@@ -284,6 +290,9 @@ __device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb, bool &di
     });
     dirty = d;
     return nb ? l1_make(ht, st) : 0u;
+}
+__device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb, bool &dirty) {
+    return piece_l1_at(lds + threadIdx.x * LDS_STRIDE, nb, dirty);
 }
 __device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb) {
     bool dirty;
@@ -351,10 +360,10 @@ __device__ __forceinline__ L2 piece_l2_clean(const uint8_t *lds, uint32_t nb, ui
 }
 
 // L2 summary of the lane's piece, given its exact incoming line state.
-__device__ __forceinline__ L2 piece_l2(const uint8_t *lds, uint32_t nb, uint32_t ls_in, uint32_t km1) {
+__device__ __forceinline__ L2 piece_l2_at(const uint8_t *mine, uint32_t nb, uint32_t ls_in, uint32_t km1) {   // mine: the piece's 64 bytes
     uint32_t ls = ls_in, flags = F_NONID, len = 0, bits = 0, rec = 0, pt = 0;
     const uint32_t bm = bases_mask(km1);
-    for_each_byte(lds, nb, [&](uint32_t i, uint32_t c, bool act) {
+    for_each_byte_of(mine, nb, [&](uint32_t i, uint32_t c, bool act) {
         const bool term = is_term(c), ws = is_ws(c), gt = c == '>';
         const bool at_start = ls == LS_START;
         const bool hdr_start = act && at_start && !ws && gt;
@@ -377,6 +386,10 @@ __device__ __forceinline__ L2 piece_l2(const uint8_t *lds, uint32_t nb, uint32_t
     if (len >= km1) flags |= F_BRK;
     L2 s; s.flags = flags | (len << 8); s.bits = bits; s.rec = rec; s.p_tail = pt;
     return s;
+}
+
+__device__ __forceinline__ L2 piece_l2(const uint8_t *lds, uint32_t nb, uint32_t ls_in, uint32_t km1) {
+    return piece_l2_at(lds + threadIdx.x * LDS_STRIDE, nb, ls_in, km1);
 }
 
 }  // namespace pk

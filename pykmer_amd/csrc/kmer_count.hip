@@ -69,27 +69,76 @@ __global__ __launch_bounds__(WG) void k_chunk_l1(const uint8_t *__restrict__ fas
     if (lane == 0) chunk_l1[chunk] = nb ? l1_make(last_term >= 0, state) : 0u;
 }
 
+// Pieces of plain sequence text are summarised four bytes at a time (L1) and from their tail (L2).  Pieces with a header,
+// a blank or a control byte -- or that start inside a header line -- need the byte-wise machines, which cost a wave the same
+// for one lane as for 64: those pieces are queued and worked off 64 per wave pass (a read set has a header every kilobase;
+// each wave then held a few such pieces and every wave took both machines).
 __global__ __launch_bounds__(WG) void k_chunk_l2(const uint8_t *__restrict__ fasta, uint64_t n_bytes,
                                                  const L1 *__restrict__ chunk_l1_state, L2 *__restrict__ chunk_l2,
-                                                 LaneState *__restrict__ lane_state, uint32_t km1) {
+                                                 LaneState *__restrict__ lane_state, uint32_t *__restrict__ chunk_odd, uint32_t km1) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[WG * LDS_STRIDE];
     __shared__ L1 sh1[WG / 64];
     __shared__ L2 sh2[WG / 64];
-    uint64_t base = (uint64_t)blockIdx.x * CHUNK;
+    __shared__ uint16_t queue[WG];
+    __shared__ uint32_t n_queued[2];
+    __shared__ uint32_t res1[WG];                          // queued pieces: L1 summary | dirty << 8
+    __shared__ uint8_t ls_of[WG];                          // every piece's incoming line state (for the L2 pass over the queue)
+    const uint64_t base = (uint64_t)blockIdx.x * CHUNK;
+    if (threadIdx.x < 2) n_queued[threadIdx.x] = 0;
     stage_chunk(fasta, base, n_bytes, lds);
     __syncthreads();
-    uint32_t nb = piece_len(base, n_bytes);
+    const uint32_t nb = piece_len(base, n_bytes);
+    const uint8_t *mine = lds + threadIdx.x * LDS_STRIDE;
+    // ---- L1: line state.  Full pieces by SWAR; what that flags as dirty, and partial pieces, go to the queue
+    bool dirty = false;
+    L1 my1 = 0u;
+    const bool full = nb == (uint32_t)PIECE;
+    if (__any(full)) my1 = piece_l1_swar(lds, dirty);      // dirty => the value is not used
+    const bool q1 = !full || dirty;
+    if (q1) queue[atomicAdd(&n_queued[0], 1u)] = (uint16_t)threadIdx.x;
+    __syncthreads();
+    for (uint32_t q0 = (threadIdx.x >> 6) * 64u; q0 < n_queued[0]; q0 += WG) {       // wave-uniform
+        const uint32_t qi = q0 + (threadIdx.x & 63u);
+        const bool work = qi < n_queued[0];
+        const uint32_t pc = work ? queue[qi] : 0u;
+        bool d;
+        const L1 r = piece_l1_at(lds + pc * LDS_STRIDE, work ? piece_len_of(pc, base, n_bytes) : 0u, d);
+        if (work) res1[pc] = r | (d ? 0x100u : 0u);
+    }
+    __syncthreads();
+    if (q1) { my1 = res1[threadIdx.x] & 0xffu; dirty = (res1[threadIdx.x] >> 8) & 1u; }
     L1 tot1;
-    bool dirty;
-    L1 my1 = piece_l1_auto(lds, nb, dirty);
-    L1 st1 = wg_excl_scan_l1(my1, chunk_l1_state[blockIdx.x], sh1, &tot1);
+    const L1 st1 = wg_excl_scan_l1(my1, chunk_l1_state[blockIdx.x], sh1, &tot1);
     const uint32_t ls_in = l1_kind(st1);
-    const bool wave_clean = __all(!dirty && ls_in != LS_HEADER);          // wave-uniform choice of path
-    L2 mine = wave_clean ? piece_l2_clean(lds, nb, ls_in, km1) : piece_l2(lds, nb, ls_in, km1);
+    ls_of[threadIdx.x] = (uint8_t)ls_in;
+    // ---- L2: record / run state.  Clean pieces from their tail; the rest through the queue again
+    const bool clean = !dirty && ls_in != LS_HEADER;
+    L2 my2 = l2_identity();
+    if (clean) my2 = piece_l2_clean(lds, nb, ls_in, km1);
+    else queue[atomicAdd(&n_queued[1], 1u)] = (uint16_t)threadIdx.x;      // the L1 queue was consumed before the scan's barriers
+    __syncthreads();
+    for (uint32_t q0 = (threadIdx.x >> 6) * 64u; q0 < n_queued[1]; q0 += WG) {
+        const uint32_t qi = q0 + (threadIdx.x & 63u);
+        const bool work = qi < n_queued[1];
+        const uint32_t pc = work ? queue[qi] : 0u;
+        const L2 r = piece_l2_at(lds + pc * LDS_STRIDE, work ? piece_len_of(pc, base, n_bytes) : 0u, ls_of[pc], km1);
+        if (work) {                                        // the result takes the place of the piece's own text, now used up
+            uint32_t *out = reinterpret_cast<uint32_t *>(lds + pc * LDS_STRIDE);
+            out[0] = r.flags; out[1] = r.bits; out[2] = r.rec; out[3] = (uint32_t)r.p_tail;     // within one piece: <= 64
+        }
+    }
+    __syncthreads();
+    if (!clean) {
+        const uint32_t *in = reinterpret_cast<const uint32_t *>(mine);
+        my2.flags = in[0]; my2.bits = in[1]; my2.rec = in[2]; my2.p_tail = in[3];
+    }
     L2 total;
-    L2 rel = wg_excl_scan_l2(mine, l2_identity(), sh2, &total, km1);     // prefix relative to the chunk start
+    const L2 rel = wg_excl_scan_l2(my2, l2_identity(), sh2, &total, km1);     // prefix relative to the chunk start
     lane_state[(uint64_t)blockIdx.x * WG + threadIdx.x] = lane_state_pack(rel, ls_in, dirty);
-    if (threadIdx.x == 0) chunk_l2[blockIdx.x] = total;
+    if (threadIdx.x == 0) {
+        chunk_l2[blockIdx.x] = total;
+        chunk_odd[blockIdx.x] = n_queued[1];               // pieces that are not plain sequence text: the squeeze pass queues them too
+    }
 }
 
 // ------------------------------------------------------------------ grid-level scans -----------
@@ -229,9 +278,9 @@ void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, L1 *
     hipLaunchKernelGGL(k_scan_l1_tiles, dim3(1), dim3(SCAN_T), 0, s, tile_ws, n_tiles, carry);
     hipLaunchKernelGGL(k_scan_l1_apply, dim3(n_tiles), dim3(SCAN_T), 0, s, in, n_chunks, (const L1 *)tile_ws, out);
 }
-void launch_chunk_l2(const uint8_t *fasta, uint64_t n, const L1 *st1, L2 *chunk_l2, LaneState *lane_state, uint32_t n_chunks, uint32_t k,
-                     hipStream_t s) {
-    hipLaunchKernelGGL(k_chunk_l2, dim3(n_chunks), dim3(WG), 0, s, fasta, n, st1, chunk_l2, lane_state, k - 1);
+void launch_chunk_l2(const uint8_t *fasta, uint64_t n, const L1 *st1, L2 *chunk_l2, LaneState *lane_state, uint32_t *chunk_odd, uint32_t n_chunks,
+                     uint32_t k, hipStream_t s) {
+    hipLaunchKernelGGL(k_chunk_l2, dim3(n_chunks), dim3(WG), 0, s, fasta, n, st1, chunk_l2, lane_state, chunk_odd, k - 1);
 }
 void launch_scan_l2(const L2 *in, uint32_t n_chunks, Carry *carry, L2 *out, L2 *tile_ws, uint32_t k, hipStream_t s) {
     const uint32_t n_tiles = (n_chunks + SCAN_T - 1) / SCAN_T;

@@ -52,8 +52,8 @@ __device__ __forceinline__ void lds_or_bits(uint32_t *dst, uint32_t at, unsigned
 }
 
 // ------------------------------------------------------------------ clean pieces, four bytes at a time ----
-// A CLEAN piece holds nothing but sequence characters and line terminators, does not start inside a header
-// line and has no blank pending in front of it (the structure pass flags everything else): no record opens,
+// A CLEAN piece holds nothing but sequence characters and line terminators and does not start inside a header
+// line (the structure pass flags everything else): no record opens,
 // nothing is stripped, every byte above 13 is a sequence character.  Then the byte-wise machine is not needed:
 // per dword, SWAR tests give "terminator", "valid base" (either case; anything else maps to None, indexer.py:36-41)
 // and the 2-bit codes of all four bytes; a multiply gathers the per-byte flags into bit masks.  On the 64-bit masks
@@ -67,12 +67,13 @@ __device__ __forceinline__ uint32_t movemask4(uint32_t flags80) {       // 0x80-
     return (flags80 * 0x00204081u) >> 28;
 }
 
-__device__ __forceinline__ void squeeze_clean(const uint8_t *piece, SeqWalker &wk, PieceBases &pb) {
-    const uint4 *mine = reinterpret_cast<const uint4 *>(piece);
+// `mine`: this lane's piece is a clean one; lanes with other pieces run along (wave-uniform loops) and leave no trace.
+__device__ __forceinline__ void squeeze_clean(const uint8_t *piece, SeqWalker &wk, PieceBases &pb, bool mine) {
+    const uint4 *quads = reinterpret_cast<const uint4 *>(piece);
     uint32_t tm[2] = {0, 0}, vm[2] = {0, 0}, cw[4] = {0, 0, 0, 0};     // terminators, valid bases, codes (byte i -> bits 2i)
 #pragma unroll
     for (int q = 0; q < PIECE / 16; q++) {
-        const uint4 v = mine[q];
+        const uint4 v = quads[q];
         const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -99,15 +100,21 @@ __device__ __forceinline__ void squeeze_clean(const uint8_t *piece, SeqWalker &w
     const unsigned long long S = ~T;                                      // sequence characters, valid or not
     const unsigned long long none = S & ~V;                               // characters that map to None
     const uint32_t n_seq = (uint32_t)__popcll(S);
-    wk.seq_acc += n_seq;                                                  // indexer.py:77: valid or not
-    const bool live = wk.rec != 0;                                        // text before the first header is dropped
+    if (mine) wk.seq_acc += n_seq;                                        // indexer.py:77: valid or not
+    // blanks pending from the piece before (that piece was not a clean one; this one is): interior if sequence text
+    // follows -- each maps to None and the run breaks -- and stripped if the line ends here (indexer.py:56)
+    if (mine && wk.pend) {
+        if (S & 1ull) { wk.seq_acc += wk.pend; wk.run = 0u; }
+        wk.pend = 0;
+    }
+    const bool live = mine && wk.rec != 0;                                // text before the first header is dropped
     // restart flags: carry from every None position through the non-base positions above it into the next base
     unsigned long long F = ((~V) + none) & V;
     if (wk.run == 0u) F |= V & (0ull - V);                                // the run was already broken when the piece began
     const uint32_t nv = (uint32_t)__popcll(V);
     // windows: compacted positions 0 .. nv-1; compact the restart flags first (delete the non-base positions)
     unsigned long long c_lo = ((unsigned long long)cw[1] << 32) | cw[0], c_hi = ((unsigned long long)cw[3] << 32) | cw[2];
-    unsigned long long holes = V ? (~V & ((1ull << (63 - __builtin_clzll(V))) - 1ull)) : 0ull;   // below the highest base only
+    unsigned long long holes = (V && mine) ? (~V & ((1ull << (63 - __builtin_clzll(V))) - 1ull)) : 0ull;   // below the highest base only
     while (__any(holes != 0ull)) {
         if (holes) {
             const uint32_t p = (uint32_t)__builtin_ctzll(holes);
@@ -190,15 +197,19 @@ __device__ __forceinline__ void stage_image(const uint8_t *__restrict__ fasta, u
 
 __global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
                                                 const LaneState *__restrict__ lane_state, const L2 *__restrict__ chunk_l2_state,
-                                                uint32_t k, uint32_t n_chunks, uint32_t chunks_per_wg, uint32_t *__restrict__ codes,
+                                                const uint32_t *__restrict__ chunk_odd, uint32_t k, uint32_t n_chunks, uint32_t chunks_per_wg,
+                                                uint32_t *__restrict__ codes,
                                                 uint32_t *__restrict__ restarts, uint32_t *__restrict__ n_bases,
                                                 DevRec *__restrict__ recs, uint64_t recs_cap, Carry *carry) {
     __shared__ __attribute__((aligned(16))) uint8_t image[2][CHUNK];
     __shared__ __attribute__((aligned(16))) uint32_t slot_codes[SLOT_CODE_WORDS + 8];   // + slack: lds_or_bits touches up to 5 words
     __shared__ __attribute__((aligned(16))) uint32_t slot_rst[SLOT_RST_WORDS + 8];
     __shared__ uint32_t scan_sh[WG / 64];
+    __shared__ uint16_t queue[WG];                         // pieces that need the byte-wise machine
+    __shared__ uint32_t n_queued;
     __shared__ RecAcc racc;
     const uint32_t km1 = k - 1;
+    if (threadIdx.x == 0) n_queued = 0;
     for (uint32_t i = threadIdx.x; i < SLOT_CODE_WORDS + 8; i += WG) slot_codes[i] = 0;
     for (uint32_t i = threadIdx.x; i < SLOT_RST_WORDS + 8; i += WG) slot_rst[i] = 0;
     recacc_init(racc);
@@ -208,29 +219,70 @@ __global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fast
     if (c_lo < c_hi) stage_image(fasta, (uint64_t)c_lo * CHUNK, n_bytes, image[0]);
     for (uint32_t c = c_lo; c < c_hi; c++) {
         const uint64_t base = (uint64_t)c * CHUNK;
-        const uint8_t *buf = image[(c - c_lo) & 1u];
+        uint8_t *buf = image[(c - c_lo) & 1u];
         __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's share of the image has landed ...
-        recacc_retarget(racc, chunk_l2_state[c].rec, recs, recs_cap);
         __syncthreads();                                   // ... and so has everyone else's; the other image is free (its readers passed the last barrier)
+        // the record tallies of a chunk count up from the record it starts in; when that moves on, what was gathered
+        // is written out (a genome keeps one window for thousands of chunks, a read set moves it with every chunk)
+        const uint32_t first_rec = chunk_l2_state[c].rec;
+        if (first_rec != racc.rec0) {                      // uniform: rec0 has not changed since the barrier
+            recacc_spill(racc, racc.rec0, recs, recs_cap);
+            __syncthreads();
+            if (threadIdx.x == 0) racc.rec0 = first_rec;
+            __syncthreads();
+        }
         if (c + 1 < c_hi) stage_image(fasta, base + CHUNK, n_bytes, image[(c - c_lo + 1) & 1u]);
-        const uint32_t nb = piece_len(base, n_bytes);
         // exact parser state at this lane's first byte: chunk state . lane prefix (both from the structure pass)
+        const L2 chunk_st = chunk_l2_state[c];
         const LaneState lst = lane_state[(uint64_t)c * WG + threadIdx.x];
-        const L2 st2 = l2_compose(chunk_l2_state[c], lane_state_l2(lst), km1);
+        const L2 st2 = l2_compose(chunk_st, lane_state_l2(lst), km1);
         const uint32_t ls_in = lane_state_ls(lst);
         wk.begin(ls_in, st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
-        const uint8_t *piece = buf + threadIdx.x * PIECE;
+        uint8_t *piece = buf + threadIdx.x * PIECE;
         PieceBases pb;
         pb.clear();
-        if (__all(!lane_state_dirty(lst) && ls_in != LS_HEADER && st2.p_tail == 0)) {     // the common case: plain sequence lines
-            squeeze_clean(piece, wk, pb);
-        } else {
-            for_each_byte_of(piece, nb, [&](uint32_t i, uint32_t ch, bool act) {
-                uint32_t code;
-                bool rst;
-                const bool take = wk.step(i, ch, act, code, rst);
-                pb.push(take, code, rst);
-            });
+        // Plain sequence text goes four bytes at a time.  Pieces with a header, a blank or a control byte need the
+        // byte-wise machine, which costs the same for one lane as for 64: they are queued, and the queue is worked
+        // off 64 pieces per wave pass -- with a header every kilobase (read sets) that is one pass per workgroup
+        // instead of one per wave.  A queued piece's result is left in the piece's own 64 bytes of the image.
+        const bool clean = !lane_state_dirty(lst) && ls_in != LS_HEADER;             // the structure pass's definition: chunk_odd counts the rest
+        const bool all_clean = chunk_odd[c] == 0u;                                  // uniform over the workgroup; the usual chunk
+        if (all_clean || __any(clean)) squeeze_clean(piece, wk, pb, clean);
+        if (!all_clean) {
+            if (!clean) queue[atomicAdd(&n_queued, 1u)] = (uint16_t)threadIdx.x;
+            __syncthreads();
+            const uint32_t n_q = n_queued;
+            for (uint32_t q0 = (threadIdx.x >> 6) * 64u; q0 < n_q; q0 += WG) {        // wave-uniform
+                const uint32_t qi = q0 + (threadIdx.x & 63u);
+                const bool work = qi < n_q;
+                const uint32_t pc = work ? queue[qi] : 0u;
+                const LaneState l2s = lane_state[(uint64_t)c * WG + pc];
+                SeqWalker wq;
+                wq.setup(k, recs, recs_cap, &racc);
+                wq.begin(lane_state_ls(l2s), l2_compose(chunk_st, lane_state_l2(l2s), km1), stream_off + base + (uint64_t)pc * PIECE);
+                const uint32_t nbq = work ? piece_len_of(pc, base, n_bytes) : 0u;
+                uint8_t *pq = buf + pc * PIECE;
+                PieceBases rb;
+                rb.clear();
+                for_each_byte_of(pq, nbq, [&](uint32_t i, uint32_t ch, bool act) {
+                    uint32_t code;
+                    bool rst;
+                    const bool take = wq.step(i, ch, act, code, rst);
+                    rb.push(take, code, rst);
+                });
+                wq.flush_rec_wave();
+                wk.seq_tot += wq.seq_tot; wk.kmer_tot += wq.kmer_tot;                  // stream totals travel with the lane that did the work
+                if (work) {
+                    unsigned long long *res = reinterpret_cast<unsigned long long *>(pq);
+                    res[0] = rb.code_lo; res[1] = rb.code_hi; res[2] = rb.restart; res[3] = rb.n;
+                }
+            }
+            __syncthreads();
+            if (!clean) {
+                const unsigned long long *res = reinterpret_cast<const unsigned long long *>(piece);
+                pb.code_lo = res[0]; pb.code_hi = res[1]; pb.restart = res[2]; pb.n = (uint32_t)res[3];
+            }
+            if (threadIdx.x == 0) n_queued = 0;                                       // read again only after the next barrier
         }
         wk.flush_rec_wave();
         // where the lane's bases go in the chunk's slot: exclusive prefix of the counts over the workgroup
@@ -257,10 +309,10 @@ __global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fast
     recacc_finish(racc, recs, recs_cap, carry);
 }
 
-void launch_squeeze(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2, uint32_t k,
-                    uint32_t n_chunks, uint32_t n_wg, uint32_t chunks_per_wg, uint32_t *codes, uint32_t *restarts, uint32_t *n_bases,
+void launch_squeeze(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2,
+                    const uint32_t *chunk_odd, uint32_t k, uint32_t n_chunks, uint32_t n_wg, uint32_t chunks_per_wg, uint32_t *codes, uint32_t *restarts, uint32_t *n_bases,
                     DevRec *recs, uint64_t recs_cap, Carry *carry, hipStream_t s) {
-    hipLaunchKernelGGL(k_squeeze, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, k, n_chunks, chunks_per_wg, codes,
+    hipLaunchKernelGGL(k_squeeze, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, chunk_odd, k, n_chunks, chunks_per_wg, codes,
                        restarts, n_bases, recs, recs_cap, carry);
 }
 

@@ -15,34 +15,40 @@
 
 namespace pk {
 
-// Per-workgroup accumulator for the record most lanes are inside of (a 16 KiB chunk usually lies in
-// one record): lanes add their tallies here, one lane writes them to HBM when the workgroup moves on
-// to another record or finishes.  Without it every lane hit the same DevRec with global atomics --
-// 25 M same-address atomics on an 800 Mbp genome, ~100 ms.
+// Per-workgroup accumulator for the records of the chunk being walked.  A 16 KiB chunk usually lies in one record,
+// a read set puts a dozen in it: lanes add their tallies to the LDS entry of their record (records of a chunk are
+// numbered consecutively from the one the chunk starts in), and once per chunk the entries are written to HBM --
+// one atomic pair per record and chunk.  Without it every lane hit the DevRec with global atomics: 25 M same-address
+// atomics on an 800 Mbp genome (~100 ms), and still two per lane and piece on a read set (~2 ms).
+constexpr uint32_t RECACC_SLOTS = 64;
 struct RecAcc {
-    uint32_t rec;                          // 1-based record the sums belong to (0 = none)
-    unsigned long long seq, kmers;         // pending sums for that record
-    unsigned long long tot_seq, tot_kmers; // stream totals gathered by this workgroup
+    uint32_t rec0;                                        // 1-based record of slot 0 (0: the chunk starts before the first header)
+    unsigned long long seq[RECACC_SLOTS], kmers[RECACC_SLOTS];   // pending sums for records rec0 .. rec0 + SLOTS - 1
+    unsigned long long tot_seq, tot_kmers;                // stream totals gathered by this workgroup
 };
 
 __device__ __forceinline__ void recacc_init(RecAcc &A) {
-    if (threadIdx.x == 0) { A.rec = 0; A.seq = 0; A.kmers = 0; A.tot_seq = 0; A.tot_kmers = 0; }
+    for (uint32_t i = threadIdx.x; i < RECACC_SLOTS; i += blockDim.x) { A.seq[i] = 0; A.kmers[i] = 0; }
+    if (threadIdx.x == 0) { A.rec0 = 0; A.tot_seq = 0; A.tot_kmers = 0; }
 }
-// thread 0 only, with the workgroup quiescent (after a barrier): write the pending sums out
-__device__ __forceinline__ void recacc_spill(RecAcc &A, DevRec *recs, uint64_t recs_cap) {
-    if (A.rec && A.rec <= recs_cap) {
-        if (A.seq) atomicAdd((unsigned long long *)&recs[A.rec - 1].seq_len, A.seq);
-        if (A.kmers) atomicAdd((unsigned long long *)&recs[A.rec - 1].n_valid, A.kmers);
+// all threads, with the workgroup's tallies of the chunk complete (after a barrier) and a barrier before the entries are
+// used again: write the pending sums out.  rec0 = the record of slot 0 as read while the chunk was being walked (thread 0
+// may already be setting A.rec0 for the next chunk).
+__device__ __forceinline__ void recacc_spill(RecAcc &A, uint32_t rec0, DevRec *recs, uint64_t recs_cap) {
+    if (threadIdx.x < RECACC_SLOTS) {
+        const uint64_t rec = (uint64_t)rec0 + threadIdx.x;
+        const unsigned long long s = A.seq[threadIdx.x], n = A.kmers[threadIdx.x];
+        if (rec && rec <= recs_cap) {
+            if (s) atomicAdd((unsigned long long *)&recs[rec - 1].seq_len, s);
+            if (n) atomicAdd((unsigned long long *)&recs[rec - 1].n_valid, n);
+        }
+        A.seq[threadIdx.x] = 0; A.kmers[threadIdx.x] = 0;
     }
-    A.seq = 0; A.kmers = 0;
-}
-__device__ __forceinline__ void recacc_retarget(RecAcc &A, uint32_t rec, DevRec *recs, uint64_t recs_cap) {
-    if (threadIdx.x == 0 && A.rec != rec) { recacc_spill(A, recs, recs_cap); A.rec = rec; }
 }
 __device__ __forceinline__ void recacc_finish(RecAcc &A, DevRec *recs, uint64_t recs_cap, Carry *carry) {
     __syncthreads();
+    recacc_spill(A, A.rec0, recs, recs_cap);
     if (threadIdx.x == 0) {
-        recacc_spill(A, recs, recs_cap);
         if (A.tot_seq) atomicAdd((unsigned long long *)&carry->total_bp, A.tot_seq);
         if (A.tot_kmers) atomicAdd((unsigned long long *)&carry->num_kmers, A.tot_kmers);
     }
@@ -93,9 +99,10 @@ struct SeqWalker {
     // May be called by any subset of lanes (a header opens mid-piece).
     __device__ __forceinline__ void flush_rec() {
         if (rec && rec <= recs_cap) {
-            if (rec == acc->rec) {
-                if (seq_acc) atomicAdd(&acc->seq, (unsigned long long)seq_acc);
-                if (kmer_acc) atomicAdd(&acc->kmers, (unsigned long long)kmer_acc);
+            const uint32_t slot = rec - acc->rec0;                       // records of a chunk count up from the one it starts in
+            if (rec >= acc->rec0 && slot < RECACC_SLOTS) {
+                if (seq_acc) atomicAdd(&acc->seq[slot], (unsigned long long)seq_acc);
+                if (kmer_acc) atomicAdd(&acc->kmers[slot], (unsigned long long)kmer_acc);
             } else {
                 if (seq_acc) atomicAdd((unsigned long long *)&recs[rec - 1].seq_len, (unsigned long long)seq_acc);
                 if (kmer_acc) atomicAdd((unsigned long long *)&recs[rec - 1].n_valid, (unsigned long long)kmer_acc);
@@ -106,16 +113,15 @@ struct SeqWalker {
         seq_acc = 0; kmer_acc = 0; name_end = 0;
     }
 
-    // End of a piece, ALL lanes of the wave: lanes inside the workgroup's current record are summed
-    // across the wave first (one LDS atomic per wave); the rest take the general path.
+    // End of a piece, ALL lanes of the wave: when the whole wave sits in one record (the usual case) the tallies are
+    // summed across the wave first (one LDS atomic pair per wave); otherwise every lane takes the general path.
     __device__ __forceinline__ void flush_rec_wave() {
-        const bool common = rec != 0 && rec == acc->rec && rec <= recs_cap;
-        unsigned long long s = common ? seq_acc : 0ull, n = common ? kmer_acc : 0ull;
-        if (common) { seq_tot += seq_acc; kmer_tot += kmer_acc; seq_acc = 0; kmer_acc = 0; }
-        for (int d = 32; d; d >>= 1) { s += __shfl_down(s, d, 64); n += __shfl_down(n, d, 64); }
-        if ((threadIdx.x & 63) == 0) {
-            if (s) atomicAdd(&acc->seq, s);
-            if (n) atomicAdd(&acc->kmers, n);
+        const uint32_t rec_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec);
+        if (__all(rec == rec_first)) {
+            unsigned long long s = seq_acc, n = kmer_acc;
+            for (int d = 32; d; d >>= 1) { s += __shfl_down(s, d, 64); n += __shfl_down(n, d, 64); }
+            const bool lead = (threadIdx.x & 63) == 0;
+            seq_acc = lead ? s : 0ull; kmer_acc = lead ? n : 0ull;      // lane 0 flushes the wave's sums; name_end stays per lane
         }
         if (seq_acc | kmer_acc | name_end) flush_rec();
     }
