@@ -80,6 +80,9 @@ int pk_indexer_finish(pk_indexer *ix, uint64_t *num_kmers_out, uint64_t *total_b
                       uint64_t hist256_out[256], uint64_t *n_recs_out);
 int pk_indexer_records(pk_indexer *ix, pk_record *recs_out, uint64_t recs_cap);
 int pk_indexer_table_to_host(pk_indexer *ix, uint8_t *table_out);
+/* Table bytes [offset, offset + n_bytes) to the host: lets the caller take the .kin image in slices and hash / write
+ * slice i while slice i+1 crosses PCIe (tools.py:280,283 hash the whole file afterwards). */
+int pk_indexer_table_slice_to_host(pk_indexer *ix, uint8_t *dst, uint64_t offset, uint64_t n_bytes);
 /* Device pointer of the finished u8 table (valid until reset/destroy) -- lets a merge run on tables
  * that never left HBM. */
 int pk_indexer_table_device(pk_indexer *ix, const void **dev_table_out);

@@ -33,6 +33,7 @@ _SIGNATURES = {
     "pk_indexer_finish": (ctypes.c_int, [ctypes.c_void_p, _u64p, _u64p, ctypes.c_void_p, _u64p]),
     "pk_indexer_records": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
     "pk_indexer_table_to_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "pk_indexer_table_slice_to_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]),
     "pk_indexer_table_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "pk_indexer_table_slice_to_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]),
     "pk_indexer_timings": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -183,7 +184,7 @@ class Indexer:
         _check(load().pk_indexer_reset(self._h))
 
     def feed(self, data):
-        buf = _as_u8(data)
+        buf = _as_u8(data)                                   # bytes, bytearray, mmap, numpy: no copy for any of them
         _check(load().pk_indexer_feed(self._h, buf.ctypes.data, buf.size))
 
     def feed_device(self, dev_ptr: int, n_bytes: int):
@@ -206,6 +207,11 @@ class Indexer:
         assert out.dtype == np.uint8 and out.size == 4 ** self.k and out.flags.c_contiguous
         _check(load().pk_indexer_table_to_host(self._h, out.ctypes.data))
         return out
+
+    def table_slice_to_host(self, out: np.ndarray, offset: int):
+        """Table bytes [offset, offset + out.size) into `out` (a contiguous uint8 array, e.g. a slice of a memmap)."""
+        assert out.dtype == np.uint8 and out.flags.c_contiguous
+        _check(load().pk_indexer_table_slice_to_host(self._h, out.ctypes.data, offset, out.size))
 
     def table_device_ptr(self) -> int:
         p = ctypes.c_void_p()

@@ -54,6 +54,100 @@ static int check_k(int k) {
     return PK_OK;
 }
 
+// ================================================================== host <-> HBM copies =========
+// The C-ABI takes plain (pageable) host buffers.  One hipMemcpy from pageable memory is a single thread bouncing
+// the bytes through a small pinned buffer; here several host threads each own a pinned bounce buffer (two halves)
+// and a stream, so page-touching memcpy and PCIe DMA of different pieces overlap and the link is what limits.
+#include <mutex>
+#include <thread>
+namespace {
+constexpr size_t BOUNCE_HALF = 8u << 20;
+constexpr int MAX_COPY_THREADS = 16;
+struct Bouncer {
+    std::mutex mu;
+    int threads = 0;
+    uint8_t *pinned[MAX_COPY_THREADS] = {};
+    hipStream_t stream[MAX_COPY_THREADS] = {};
+    hipEvent_t ev[MAX_COPY_THREADS][2] = {};
+};
+Bouncer g_bounce[64];
+
+int bouncer_for(int device, Bouncer **out) {
+    if (device < 0 || device >= 64) return fail(PK_ERR_ARG, "device ordinal %d out of range", device);
+    Bouncer &b = g_bounce[device];
+    static std::mutex init_mu;                             // several host threads may make their first copy at once
+    std::lock_guard<std::mutex> init_lock(init_mu);
+    if (!b.threads) {
+        const char *env = getenv("PK_COPY_THREADS");
+        int t = env ? atoi(env) : 8;
+        t = std::max(1, std::min(t, MAX_COPY_THREADS));
+        for (int i = 0; i < t; i++) {
+            HIPCHK(hipHostMalloc((void **)&b.pinned[i], 2 * BOUNCE_HALF, hipHostMallocDefault));
+            HIPCHK(hipStreamCreateWithFlags(&b.stream[i], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&b.ev[i][0], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&b.ev[i][1], hipEventDisableTiming));
+        }
+        b.threads = t;
+    }
+    *out = &b;
+    return PK_OK;
+}
+
+// to_device: host -> dev, else dev -> host.  Blocking.
+int bounce_copy(void *dev, void *host, size_t n, bool to_device, int device) {
+    if (n == 0) return PK_OK;
+    HIPCHK(hipSetDevice(device));
+    if (n < (4u << 20)) {
+        HIPCHK(to_device ? hipMemcpy(dev, host, n, hipMemcpyHostToDevice) : hipMemcpy(host, dev, n, hipMemcpyDeviceToHost));
+        return PK_OK;
+    }
+    Bouncer *b = nullptr;
+    int rc = bouncer_for(device, &b);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(b->mu);
+    const size_t n_pieces = (n + BOUNCE_HALF - 1) / BOUNCE_HALF;
+    const int T = (int)std::min<size_t>((size_t)b->threads, n_pieces);
+    std::vector<hipError_t> errs(T, hipSuccess);
+    auto work = [&](int t) {
+        hipError_t e = hipSetDevice(device);
+        size_t pending_off[2] = {0, 0}, pending_len[2] = {0, 0};      // D2H: a half whose DMA is in flight and still has to reach the host buffer
+        int h = 0;
+        for (size_t p = (size_t)t; p < n_pieces && e == hipSuccess; p += (size_t)T, h ^= 1) {
+            const size_t off = p * BOUNCE_HALF, len = std::min(BOUNCE_HALF, n - off);
+            uint8_t *half = b->pinned[t] + (size_t)h * BOUNCE_HALF;
+            if (to_device) {
+                e = hipEventSynchronize(b->ev[t][h]);                  // the DMA that last read this half is done
+                if (e != hipSuccess) break;
+                memcpy(half, (const uint8_t *)host + off, len);
+                e = hipMemcpyAsync((uint8_t *)dev + off, half, len, hipMemcpyHostToDevice, b->stream[t]);
+                if (e == hipSuccess) e = hipEventRecord(b->ev[t][h], b->stream[t]);
+            } else {
+                if (pending_len[h]) {                                  // drain what this half held before reusing it
+                    e = hipEventSynchronize(b->ev[t][h]);
+                    if (e != hipSuccess) break;
+                    memcpy((uint8_t *)host + pending_off[h], half, pending_len[h]);
+                }
+                e = hipMemcpyAsync(half, (const uint8_t *)dev + off, len, hipMemcpyDeviceToHost, b->stream[t]);
+                if (e == hipSuccess) e = hipEventRecord(b->ev[t][h], b->stream[t]);
+                pending_off[h] = off; pending_len[h] = len;
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream[t]);
+        if (!to_device && e == hipSuccess)
+            for (int q = 0; q < 2; q++)
+                if (pending_len[q]) memcpy((uint8_t *)host + pending_off[q], b->pinned[t] + (size_t)q * BOUNCE_HALF, pending_len[q]);
+        errs[t] = e;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    for (int t = 0; t < T; t++)
+        if (errs[t] != hipSuccess) return fail(PK_ERR_HIP, "host <-> device copy failed: %s", hipGetErrorString(errs[t]));
+    return PK_OK;
+}
+}  // namespace
+
 // ================================================================== device buffers =============
 extern "C" int pk_dev_alloc(void **dev_out, uint64_t n_bytes, int device) {
     if (!dev_out) return fail(PK_ERR_ARG, "null output pointer");
@@ -69,15 +163,11 @@ extern "C" int pk_dev_free(void *dev, int device) {
 }
 extern "C" int pk_dev_upload(void *dev_dst, const void *host_src, uint64_t n_bytes, int device) {
     if (n_bytes && (!dev_dst || !host_src)) return fail(PK_ERR_ARG, "null pointer");
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipMemcpy(dev_dst, host_src, n_bytes, hipMemcpyHostToDevice));
-    return PK_OK;
+    return bounce_copy(dev_dst, const_cast<void *>(host_src), n_bytes, true, device);
 }
 extern "C" int pk_dev_download(void *host_dst, const void *dev_src, uint64_t n_bytes, int device) {
     if (n_bytes && (!host_dst || !dev_src)) return fail(PK_ERR_ARG, "null pointer");
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipMemcpy(host_dst, dev_src, n_bytes, hipMemcpyDeviceToHost));
-    return PK_OK;
+    return bounce_copy(const_cast<void *>(dev_src), host_dst, n_bytes, false, device);
 }
 
 extern "C" int pk_dev_mem_info(uint64_t *free_out, uint64_t *total_out, int device) {
@@ -306,8 +396,9 @@ extern "C" int pk_indexer_feed(pk_indexer *ix, const uint8_t *host_fasta, uint64
             HIPCHK(hipMalloc(&ix->staging, len + 64));
             ix->staging_cap = len + 64;
         }
-        HIPCHK(hipMemcpyAsync(ix->staging, host_fasta + off, len, hipMemcpyHostToDevice, ix->stream));
-        int rc = pk_indexer_feed_device(ix, ix->staging, len);
+        int rc = bounce_copy(ix->staging, const_cast<uint8_t *>(host_fasta) + off, len, true, ix->device);
+        if (rc) return rc;
+        rc = pk_indexer_feed_device(ix, ix->staging, len);
         if (rc) return rc;
     }
     return PK_OK;
@@ -367,9 +458,14 @@ extern "C" int pk_indexer_records(pk_indexer *ix, pk_record *recs_out, uint64_t 
 extern "C" int pk_indexer_table_to_host(pk_indexer *ix, uint8_t *table_out) {
     if (!ix || !table_out) return fail(PK_ERR_ARG, "null argument");
     if (!ix->finished) return fail(PK_ERR_STATE, "call pk_indexer_finish first");
-    HIPCHK(hipSetDevice(ix->device));
-    HIPCHK(hipMemcpy(table_out, ix->table8, ix->n, hipMemcpyDeviceToHost));
-    return PK_OK;
+    return bounce_copy(ix->table8, table_out, ix->n, false, ix->device);
+}
+
+extern "C" int pk_indexer_table_slice_to_host(pk_indexer *ix, uint8_t *dst, uint64_t offset, uint64_t n_bytes) {
+    if (!ix || !dst) return fail(PK_ERR_ARG, "null argument");
+    if (!ix->finished) return fail(PK_ERR_STATE, "call pk_indexer_finish first");
+    if (offset > ix->n || n_bytes > ix->n - offset) return fail(PK_ERR_ARG, "slice outside the table");
+    return bounce_copy(ix->table8 + offset, dst, n_bytes, false, ix->device);
 }
 
 extern "C" int pk_indexer_table_device(pk_indexer *ix, const void **dev_table_out) {
@@ -482,6 +578,8 @@ GramCtx g_gram[MAX_DEVICES];
 int gram_ctx(int device, GramCtx **out) {
     if (device < 0 || device >= MAX_DEVICES) return fail(PK_ERR_ARG, "device ordinal %d out of range", device);
     GramCtx &c = g_gram[device];
+    static std::mutex init_mu;
+    std::lock_guard<std::mutex> init_lock(init_mu);
     if (!c.d_ptrs) {
         HIPCHK(hipMalloc(&c.d_ptrs, 128 * sizeof(void *)));
         HIPCHK(hipMalloc(&c.d_pair, 128 * 128 * sizeof(unsigned long long)));

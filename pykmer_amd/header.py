@@ -345,7 +345,8 @@ class Header(HeaderVars):
             part, delivered = bgzf.decompress_range(path, lo, hi)
         else:
             assert os.path.getsize(path) == self.data_size, f"{path}: not {self.data_size} bytes"
-            part = np.fromfile(path, dtype=np.uint8, count=hi - lo, offset=lo)
+            # a view of the page cache, not a copy: the library moves it to HBM from several threads
+            part = np.memmap(path, dtype=np.uint8, mode="r", offset=lo, shape=(hi - lo,)) if hi > lo else np.zeros(0, np.uint8)
             delivered = part.size
         assert part.size == hi - lo, f"{path}: short read"
         self.bytes_delivered = getattr(self, "bytes_delivered", 0) + delivered

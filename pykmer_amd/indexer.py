@@ -49,48 +49,125 @@ def _names_from_stream(input_file: str, records: np.ndarray) -> List[bytes]:
     return names
 
 
-def _pieces(input_file: str):
-    """The decompressed byte stream in FEED_BYTES pieces.  A BGZF-compressed FASTA (bgzip output) is
-    inflated block-parallel in one go when it is small enough to keep; everything else streams."""
-    if input_file.endswith((".gz", ".bgz")):
-        from . import bgzf
-        if bgzf.is_bgzf(input_file) and os.path.getsize(input_file) * 6 <= RESIDENT_LIMIT:
-            print(f"READING FASTA FROM BGZF {input_file}")
-            data = bgzf.decompress_file(input_file)
-            for off in range(0, data.size, FEED_BYTES):
-                yield data[off:off + FEED_BYTES].tobytes()
-            return
-    with _open_input(input_file) as fh:
-        while True:
-            piece = fh.read(FEED_BYTES)
-            if not piece:
+class _Input:
+    """The decompressed byte stream of a FASTA file, in FEED_BYTES pieces (anything with the buffer protocol), and
+    afterwards the header texts at given byte ranges of that stream.
+
+    A plain file is mapped, not read: the pieces are views of the page cache that the library copies to HBM from
+    several threads, and the names are sliced from the mapping.  A BGZF-compressed FASTA (bgzip output) is inflated
+    block-parallel in one go when it is small enough to keep.  Other gzip streams are read through gzip.open like
+    the reference does (indexer.py:112-115); their pieces are kept for the names while they fit RESIDENT_LIMIT,
+    otherwise the stream is inflated a second time."""
+
+    def __init__(self, input_file: str):
+        self.path = input_file
+        self.gz = input_file.endswith((".gz", ".bgz"))
+        self.whole = None                   # BGZF: the inflated stream
+        self.kept, self.kept_bytes = [], 0  # gzip: pieces in order, or None once they no longer fit
+
+    def pieces(self):
+        if not self.gz:
+            print(f"READING FASTA FROM {self.path}")
+            if os.path.getsize(self.path) == 0:
                 return
-            yield piece
+            import mmap
+            with open(self.path, "rb") as fh:
+                mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+            arr = np.frombuffer(mm, dtype=np.uint8)
+            for off in range(0, arr.size, FEED_BYTES):
+                yield arr[off:off + FEED_BYTES]
+            del arr
+            try:
+                mm.close()
+            except BufferError:                             # a caller still holds a piece: the mapping goes with it
+                pass
+            return
+        from . import bgzf
+        if bgzf.is_bgzf(self.path) and os.path.getsize(self.path) * 6 <= RESIDENT_LIMIT:
+            print(f"READING FASTA FROM BGZF {self.path}")
+            self.whole = bgzf.decompress_file(self.path)
+            for off in range(0, self.whole.size, FEED_BYTES):
+                yield self.whole[off:off + FEED_BYTES]
+            return
+        with _open_input(self.path) as fh:
+            while True:
+                piece = fh.read(FEED_BYTES)
+                if not piece:
+                    return
+                if self.kept is not None:
+                    self.kept.append(piece)
+                    self.kept_bytes += len(piece)
+                    if self.kept_bytes > RESIDENT_LIMIT:
+                        self.kept = None
+                yield piece
+
+    def names(self, records: np.ndarray) -> List[bytes]:
+        spans = [(int(r["name_off"]), int(r["name_len"])) for r in records]
+        if not spans:
+            return []
+        if not self.gz:
+            import mmap
+            with open(self.path, "rb") as fh, mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+                return [mm[off:off + ln] for off, ln in spans]
+        if self.whole is not None:
+            return [self.whole[off:off + ln].tobytes() for off, ln in spans]
+        if self.kept is not None:
+            blob = self.kept[0] if len(self.kept) == 1 else b"".join(self.kept)
+            return [blob[off:off + ln] for off, ln in spans]
+        return _names_from_stream(self.path, records)
 
 
-def count_file(input_file: str, kmer_len: int, device: int = 0):
+TABLE_SLICE = 64 << 20          # the table leaves HBM in slices: slice i is hashed while slice i+1 crosses PCIe
+
+
+def count_file(input_file: str, kmer_len: int, device: int = 0, table_file: str = None):
     """Streams one FASTA file through the GPU indexer.
 
-    Returns (table u8[4^k] on the host, summary dict, all_records [(name, seq_len, n_valid)])."""
-    kept, total = [], 0
+    Returns (table, summary dict, all_records [(name, seq_len, n_valid)]).  With `table_file` the 4^k-byte
+    table is written straight into that file (tools.py:333-341: exactly 4^k bytes, no header) slice by slice as
+    it arrives, hashed on the way (summary["table_sha256"]), and `table` is the mapping of the file; otherwise
+    `table` is a host array."""
+    import hashlib
+    import queue
+    import threading
+    source = _Input(input_file)
     with _lib.Indexer(kmer_len, device=device) as ix:
-        for piece in _pieces(input_file):
+        for piece in source.pieces():
             ix.feed(piece)
-            total += len(piece)
-            if kept is not None:
-                kept.append(piece)
-                if total > RESIDENT_LIMIT:
-                    kept = None
         fin = ix.finish()
         recs = ix.records(fin["n_records"])
-        table = ix.table_to_host()
         fin["timings"] = ix.timings()
-    if kept is not None:
-        blob = kept[0] if len(kept) == 1 else b"".join(kept)
-        raw = [blob[int(r["name_off"]): int(r["name_off"]) + int(r["name_len"])] for r in recs]
-    else:
-        raw = _names_from_stream(input_file, recs)
-    everything = [(n.decode("utf-8", "replace"), int(r["seq_len"]), int(r["n_valid_kmers"])) for n, r in zip(raw, recs)]
+        n = 4 ** kmer_len
+        if table_file is None:
+            table = ix.table_to_host()
+        else:
+            with open(table_file, "wb") as fh:
+                fh.truncate(n)
+            table = np.memmap(table_file, dtype=np.uint8, mode="r+", shape=(n,))
+            digest = hashlib.sha256()
+            todo: "queue.Queue" = queue.Queue()
+
+            def hasher():
+                while True:
+                    part = todo.get()
+                    if part is None:
+                        return
+                    digest.update(part)                        # hashlib releases the GIL
+
+            worker = threading.Thread(target=hasher)
+            worker.start()
+            try:
+                for off in range(0, n, TABLE_SLICE):
+                    part = table[off:min(n, off + TABLE_SLICE)]
+                    ix.table_slice_to_host(part, off)
+                    todo.put(part)
+            finally:
+                todo.put(None)
+                worker.join()
+            table.flush()
+            fin["table_sha256"] = digest.hexdigest()
+    raw = source.names(recs)                                   # header text: byte ranges of the decompressed stream
+    everything = [(nm.decode("utf-8", "replace"), int(r["seq_len"]), int(r["n_valid_kmers"])) for nm, r in zip(raw, recs)]
     return table, fin, everything
 
 
@@ -114,15 +191,15 @@ def create_fasta_index(
     print(f"project_name {header.project_name} sample_name {header.sample_name} kmer_len {header.kmer_len:15,d} "
           f"kmer_size {header.kmer_size:15,d} max_size {header.max_size:15,d} bytes {header.max_size // 1024:15,d} Kb "
           f"{header.max_size // 1024 // 1024:15,d} Mb {header.max_size // 1024 // 1024 // 1024:15,d} Gb")
-    header._init_clean(overwrite=overwrite)                    # indexer.py:327 (the sparse tmp file is written whole below)
+    header._init_clean(overwrite=overwrite)                    # indexer.py:327 (the tmp file is written whole below)
 
     # the two sha256 sums of the .kin.json (tools.py:280,283) run beside the work instead of after it: the input
-    # file is hashed while the GPU counts, the table while it is written (hashlib releases the GIL)
+    # file is hashed in a thread while the GPU counts, the table slice by slice as it comes back from HBM
     import concurrent.futures
-    import hashlib
-    pool = concurrent.futures.ThreadPoolExecutor(max_workers=2)
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
     input_sum = pool.submit(gen_checksum, header.input_file_path, 1 << 22)
-    table, fin, everything = count_file(input_file, kmer_len, device=device)
+    table, fin, everything = count_file(input_file, kmer_len, device=device, table_file=header.index_tmp_file)
+    del table
     for num, (name, seq_len, n_valid) in enumerate(everything):
         print(f"{num + 1:03d} {name} {seq_len:15,d}")           # indexer.py:136
     header.timer.update(fin["total_bp"])
@@ -131,12 +208,8 @@ def create_fasta_index(
     header.chromosomes = [(name, seq_len) for name, seq_len, n_valid in everything if n_valid]
     print(f"project_name {header.project_name} kmer_len {header.kmer_len:15,d} num_kmers {header.num_kmers:15,d} "
           f"kmer_size {header.kmer_size:15,d} max_size {header.max_size:15,d}")
-
-    table_sum = pool.submit(lambda: hashlib.sha256(memoryview(table)).hexdigest())
-    with open(header.index_tmp_file, "wb") as fh:              # tools.py:333-341: exactly 4^k bytes, no header
-        table.tofile(fh)
     print("  indexing finished. creating header")
-    checksums = {"input": input_sum.result(), "output": table_sum.result()}
+    checksums = {"input": input_sum.result(), "output": fin["table_sha256"]}
     pool.shutdown()
     header.write_metadata_index_tmp_file(hist256=fin["hist256"], checksums=checksums)   # asserts num_kmers and chromosomes (tools.py:367-368)
     print("renaming")
