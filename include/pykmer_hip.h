@@ -64,6 +64,10 @@ int pk_count_fasta(const uint8_t *fasta, uint64_t n_bytes, int k, uint8_t *table
                    uint64_t *num_kmers_out, uint64_t *total_bp_out, uint64_t hist256_out[256],
                    pk_record *recs_out, uint64_t recs_cap, uint64_t *n_recs_out, int device);
 
+/* pk_count_fasta keeps its indexer (table + workspace in HBM) for the next call with the same k and device;
+ * this frees it. */
+int pk_count_release(void);
+
 /* Streaming / device-resident form of the same path (inputs larger than host RAM, inputs that
  * already live in HBM, repeated timing).  One indexer owns one 4^k table in HBM on one device. */
 typedef struct pk_indexer pk_indexer;

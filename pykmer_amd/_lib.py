@@ -26,6 +26,7 @@ _SIGNATURES = {
     "pk_dev_mem_info": (ctypes.c_int, [_u64p, _u64p, ctypes.c_int]),
     "pk_count_fasta": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, _u64p, _u64p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, _u64p, ctypes.c_int]),
+    "pk_count_release": (ctypes.c_int, []),
     "pk_indexer_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
     "pk_indexer_reset": (ctypes.c_int, [ctypes.c_void_p]),
     "pk_indexer_feed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),

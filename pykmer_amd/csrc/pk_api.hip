@@ -196,8 +196,8 @@ struct pk_indexer {
     L1 *t_l1 = nullptr;                // scan scratch: one summary per 1024 chunks
     L2 *t_l2 = nullptr;
     uint32_t chunk_cap = 0;
-    uint8_t *staging = nullptr;      // device copy of host-fed bytes
-    uint64_t staging_cap = 0;
+    uint8_t *staging[2] = {nullptr, nullptr};   // device copies of host-fed pieces (one counted while the next uploads)
+    uint64_t staging_cap[2] = {0, 0};
     uint64_t bytes_fed = 0, n_recs = 0;
     bool finished = false;
     hipEvent_t ev[12] = {};
@@ -238,7 +238,7 @@ extern "C" void pk_indexer_destroy(pk_indexer *ix) {
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
     hipFree(ix->table8); hipFree(ix->carry); hipFree(ix->hist); hipFree(ix->recs);
-    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state); hipFree(ix->chunk_odd); hipFree(ix->t_l1); hipFree(ix->t_l2); hipFree(ix->staging); hipFree(ix->ws);
+    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state); hipFree(ix->chunk_odd); hipFree(ix->t_l1); hipFree(ix->t_l2); hipFree(ix->staging[0]); hipFree(ix->staging[1]); hipFree(ix->ws);
     for (auto &e : ix->ev) if (e) hipEventDestroy(e);
     if (ix->stream) hipStreamDestroy(ix->stream);
     delete ix;
@@ -383,23 +383,41 @@ extern "C" int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uin
     return PK_OK;
 }
 
+// Host text arrives in pieces of FEED_PIECE bytes through two staging buffers in HBM: while the GPU counts piece i,
+// the copy threads already move piece i+1 across PCIe (the upload, ~15 ms per 0.8 GB, is the longer of the two).
 extern "C" int pk_indexer_feed(pk_indexer *ix, const uint8_t *host_fasta, uint64_t n_bytes) {
     if (!ix) return fail(PK_ERR_ARG, "null indexer");
     if (n_bytes == 0) return PK_OK;
     if (!host_fasta) return fail(PK_ERR_ARG, "null FASTA pointer");
     HIPCHK(hipSetDevice(ix->device));
-    const uint64_t PIECE_MAX = 1ULL << 30;               // stage at most 1 GiB at a time
-    for (uint64_t off = 0; off < n_bytes; off += PIECE_MAX) {
-        uint64_t len = std::min(PIECE_MAX, n_bytes - off);
-        if (len + 64 > ix->staging_cap) {
-            hipFree(ix->staging); ix->staging = nullptr; ix->staging_cap = 0;
-            HIPCHK(hipMalloc(&ix->staging, len + 64));
-            ix->staging_cap = len + 64;
+    const char *env = getenv("PK_FEED_PIECE");
+    uint64_t piece = env ? strtoull(env, nullptr, 10) : (256ULL << 20);
+    piece = std::max<uint64_t>(1 << 20, std::min<uint64_t>(piece, 1ULL << 30)) & ~15ULL;
+    const uint64_t n_pieces = (n_bytes + piece - 1) / piece;
+    const uint64_t buf_bytes = std::min(piece, n_bytes) + 64;
+    const int n_bufs = n_pieces > 1 ? 2 : 1;
+    for (int i = 0; i < n_bufs; i++)
+        if (buf_bytes > ix->staging_cap[i]) {
+            hipFree(ix->staging[i]); ix->staging[i] = nullptr; ix->staging_cap[i] = 0;
+            HIPCHK(hipMalloc(&ix->staging[i], buf_bytes));
+            ix->staging_cap[i] = buf_bytes;
         }
-        int rc = bounce_copy(ix->staging, const_cast<uint8_t *>(host_fasta) + off, len, true, ix->device);
+    auto upload = [&](uint64_t p) -> int {
+        const uint64_t off = p * piece, len = std::min(piece, n_bytes - off);
+        return bounce_copy(ix->staging[p & 1], const_cast<uint8_t *>(host_fasta) + off, len, true, ix->device);
+    };
+    int rc = upload(0);
+    if (rc) return rc;
+    for (uint64_t p = 0; p < n_pieces; p++) {
+        int up_rc = PK_OK;
+        std::string up_err;
+        std::thread next;
+        if (p + 1 < n_pieces) next = std::thread([&]() { up_rc = upload(p + 1); if (up_rc) up_err = g_err; });
+        const uint64_t off = p * piece, len = std::min(piece, n_bytes - off);
+        rc = pk_indexer_feed_device(ix, ix->staging[p & 1], len);
+        if (next.joinable()) next.join();
         if (rc) return rc;
-        rc = pk_indexer_feed_device(ix, ix->staging, len);
-        if (rc) return rc;
+        if (up_rc) { g_err = up_err; return up_rc; }
     }
     return PK_OK;
 }
@@ -492,6 +510,13 @@ extern "C" int pk_indexer_timings(pk_indexer *ix, double out[10]) {
     return PK_OK;
 }
 
+static pk_indexer *g_cached_indexer = nullptr;
+
+extern "C" int pk_count_release(void) {
+    if (g_cached_indexer) { pk_indexer_destroy(g_cached_indexer); g_cached_indexer = nullptr; }
+    return PK_OK;
+}
+
 extern "C" int pk_count_fasta(const uint8_t *fasta, uint64_t n_bytes, int k, uint8_t *table_out, uint64_t *num_kmers_out,
                               uint64_t *total_bp_out, uint64_t hist256_out[256], pk_record *recs_out, uint64_t recs_cap,
                               uint64_t *n_recs_out, int device) {
@@ -499,10 +524,19 @@ extern "C" int pk_count_fasta(const uint8_t *fasta, uint64_t n_bytes, int k, uin
     if (rc) return rc;
     if (!table_out) return fail(PK_ERR_ARG, "null table pointer");
     if (n_bytes && !fasta) return fail(PK_ERR_ARG, "null FASTA pointer");
-    pk_indexer *ix = nullptr;
-    rc = pk_indexer_create(&ix, k, device);
-    if (rc) return rc;
-    auto done = [&](int r) { std::string keep = g_err; pk_indexer_destroy(ix); g_err = keep; return r; };
+    // one indexer (1 GiB .. 16 GiB table + workspace in HBM) is kept between calls for the same k and device: a caller
+    // that counts sample after sample does not pay hipMalloc / hipFree of ~15 GB each time.  pk_count_release() frees it.
+    static std::mutex cache_mu;
+    std::lock_guard<std::mutex> cache_lock(cache_mu);
+    pk_indexer *&ix = g_cached_indexer;
+    if (ix && (ix->k != k || ix->device != device)) { pk_indexer_destroy(ix); ix = nullptr; }
+    if (!ix) {
+        rc = pk_indexer_create(&ix, k, device);
+        if (rc) { ix = nullptr; return rc; }
+    } else if ((rc = pk_indexer_reset(ix))) {
+        return rc;
+    }
+    auto done = [&](int r) { return r; };
     if ((rc = pk_indexer_feed(ix, fasta, n_bytes))) return done(rc);
     uint64_t n_recs = 0;
     if ((rc = pk_indexer_finish(ix, num_kmers_out, total_bp_out, hist256_out, &n_recs))) return done(rc);
