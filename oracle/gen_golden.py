@@ -140,8 +140,8 @@ def load_manifest():
 def save_manifest(m):
     os.makedirs(GOLDEN, exist_ok=True)
     cur = load_manifest()                      # merge: several groups may be generated concurrently
-    for section in ("indexer", "merger"):
-        cur[section].update(m[section])
+    for section in ("indexer", "merger", "bgzf"):
+        cur.setdefault(section, {}).update(m.get(section, {}))
     m = cur
     with open(os.path.join(GOLDEN, "manifest.json"), "w") as fh:
         json.dump(m, fh, indent=1, sort_keys=True)
@@ -226,10 +226,39 @@ def group_merge(m):
         print(f"[golden] merge {tag}: shared[0,1]={matrix[0, 1, 2]} took {time.time() - t0:.0f}s", flush=True)
 
 
+def group_bgzf(m):
+    """f1/f2: a .kin.bgz + .gzi written by THIS build's BGZF writer (the reference shells out to htslib's bgzip,
+    README.md:26, which is not in the image), read back by the reference's own tools: gzireader.print_index on
+    the index, and tools.Header.open_file -> gzip.open on the table (tools.py:294-305).  What the reference printed
+    and what it read are committed; tests/test_bgzf.py regenerates the file and compares."""
+    from pykmer_amd import bgzf
+    _import_reference()
+    import gzireader                                                      # the reference's reader of the index layout
+    os.makedirs(SCRATCH, exist_ok=True)
+    spec = {"gen": "bgzf_table", "n": 300_000, "seed": 77}
+    table = inputs.make_input(spec)
+    raw = os.path.join(SCRATCH, "bgzf_case.07.kin")
+    with open(raw, "wb") as fh:
+        fh.write(table)
+    dst, gzi = bgzf.compress_file(raw, level=9, threads=2)
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        gzireader.print_index(gzi)
+    with gzip.open(dst, "rb") as fh:                                      # what tools.py:300-302 does with a .bgz
+        back = fh.read()
+    assert back == bytes(table)
+    m.setdefault("bgzf", {})["gzi_300k_level9"] = {
+        "input": spec, "input_sha256": hashlib.sha256(bytes(table)).hexdigest(), "level": 9,
+        "bgz_sha256": sha256_file(dst), "gzi_sha256": sha256_file(gzi),
+        "gzireader_stdout": out.getvalue(), "gzip_open_sha256": hashlib.sha256(back).hexdigest(),
+        "zlib_version": __import__("zlib").ZLIB_VERSION}
+    print(f"[golden] bgzf: reference gzireader printed {len(out.getvalue().splitlines())} lines", flush=True)
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "small"
     m = {"indexer": {}, "merger": {}}
-    groups = {"small": group_small, "k15": group_k15, "k17": group_k17, "full": group_full, "merge": group_merge}
+    groups = {"small": group_small, "k15": group_k15, "k17": group_k17, "full": group_full, "merge": group_merge, "bgzf": group_bgzf}
     for name in (groups if what == "all" else [what]):
         groups[name](m)
         save_manifest(m)

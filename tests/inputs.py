@@ -87,6 +87,14 @@ def make_input(spec: dict) -> bytes:
         data = synth.c2(**spec.get("args", {}))[0].tobytes()
     elif kind == "family":
         data = synth.family(**spec["args"])[0].tobytes()
+    elif kind == "bgzf_table":                        # a count-table-like byte string: mostly zeros, small counts (seeded, numpy-free stream)
+        import struct
+        x, out = spec["seed"] * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF, bytearray()
+        for _ in range(spec["n"]):
+            x = (x * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+            r = x >> 40
+            out.append(0 if r % 10 < 7 else 1 + (r >> 8) % 5)
+        data = bytes(out)
     else:
         raise KeyError(kind)
     return data

@@ -114,3 +114,33 @@ def test_decompress_range_reads_only_covering_blocks(tmp_path):
         fh.write(data.tobytes())
     part, inflated = bgzf.decompress_range(str(plain), 300_000, 300_100)
     assert np.array_equal(part, data[300_000:300_100]) and inflated == 300_100
+
+
+def test_gzi_and_bgz_as_the_reference_reads_them(tmp_path, manifest):
+    """Pinned by the reference's own tools (oracle/gen_golden.py bgzf, build container): its gzireader.print_index
+    printed `gzireader_stdout` for the .gzi this writer produced, and tools.py:300-302's gzip.open read the table
+    back.  Here the same seeded table is compressed again: the index must list what the reference printed and
+    python's gzip must return the table.  Byte identity of the compressed file holds for the same zlib only."""
+    import hashlib
+    import zlib
+    import inputs
+    case = manifest["bgzf"]["gzi_300k_level9"]
+    table = inputs.make_input(case["input"])
+    assert hashlib.sha256(table).hexdigest() == case["input_sha256"]
+    raw = tmp_path / "bgzf_case.07.kin"
+    raw.write_bytes(table)
+    dst, gzi = bgzf.compress_file(str(raw), level=case["level"], threads=2)
+    with gzip.open(dst, "rb") as fh:
+        assert hashlib.sha256(fh.read()).hexdigest() == case["gzip_open_sha256"]
+    entries = bgzf.read_gzi(gzi)
+    size = os.path.getsize(dst)
+    lines = [f"number_entries: {len(entries):15,d}", f"filesize      : {size:15,d}"]
+    lines += [f"pos: {i:15,d} compressed_offset {c:15,d} uncompressed_offset {u:15,d}" for i, (c, u) in enumerate(entries)]
+    lines += lines[:2]
+    want = case["gzireader_stdout"].splitlines()
+    assert [ln.split("compressed_offset")[0] for ln in lines] == [ln.split("compressed_offset")[0] for ln in want]
+    assert [ln.split("uncompressed_offset")[-1] for ln in lines[2:-2]] == [ln.split("uncompressed_offset")[-1] for ln in want[2:-2]]
+    if zlib.ZLIB_VERSION == case["zlib_version"]:
+        assert lines == want
+        assert hashlib.sha256(open(dst, "rb").read()).hexdigest() == case["bgz_sha256"]
+        assert hashlib.sha256(open(gzi, "rb").read()).hexdigest() == case["gzi_sha256"]
