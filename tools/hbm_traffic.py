@@ -16,8 +16,8 @@ import re
 import sys
 
 PIPELINE = ("k_chunk_l1", "k_chunk_l2", "k_scan_l1_reduce", "k_scan_l1_tiles", "k_scan_l1_apply", "k_scan_l2_reduce",
-            "k_scan_l2_tiles", "k_scan_l2_apply", "k_walk_flat", "k_rows1_scan", "k_scatter1", "k_fine_sum", "k_fine_scan", "k_count2", "k_rows2_scan",
-            "k_scatter2", "k_bucket_count", "k_hist_reduce", "k_apply_side")
+            "k_scan_l2_tiles", "k_scan_l2_apply", "k_squeeze", "k_walk_sort_count", "k_tally_sum", "k_provision", "k_walk_sort",
+            "k_level1_finish", "k_count2", "k_rows2_scan", "k_scatter2", "k_bucket_count", "k_hist_reduce", "k_apply_side")
 
 
 def short(name: str) -> str:
@@ -27,6 +27,8 @@ def short(name: str) -> str:
     base = m.group(1)
     if base.startswith("k_gram") and m.group(2):
         return base + "<" + m.group(2)[1:-1].split(",")[0] + ">"
+    if base == "k_walk_sort" and re.search(r"k_walk_sort<[^,]+, true", name):
+        return "k_walk_sort_count"                                   # the sampling launch (tallies only)
     return base
 
 
@@ -50,6 +52,8 @@ def main() -> None:
                  "largest dispatch per kernel (= the 800 Mbp k=15 step); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                  "MI355X_MICROARCH.md HBM section (FETCH_SIZE reads half of a wide coalesced stream on gfx950). "
                  "Calibration: k_gram_blk (N=32) vs 34.36 GB algorithmic; k_chunk_l2 vs 0.813 GB FASTA + 0.203 GB lane states. "
+                 "The factor 2 is calibrated for 16-byte-per-lane streams only; k_walk_sort reads 4 bytes per lane (0.3 GB of packed "
+                 "bases) and k_squeeze reads by LDS-DMA, so their read side is approximate -- their traffic is mostly writes. "
                  "Derived by tools/hbm_traffic.py.",
         "_source": [fetch_csv, write_csv],
     }

@@ -2,12 +2,14 @@
 # copies what tools/profile_round.sh collected (gpurun_out/profile_round) into profiles/ and derives hbm_traffic.json
 set -e
 cd "$(dirname "$0")/.."
-O=gpurun_out/profile_round; P=profiles; R=${1:-round01_final}
+O=gpurun_out/profile_round; P=profiles; R=${1:-round02}
 cp $O/bench.json $P/${R}_bench.json
 cp $O/stats/ks_kernel_stats.csv $P/${R}_kernel_stats.csv
 cp $O/bench_under_rocprof.json $P/${R}_bench_under_rocprof.json
 cp $O/pmc_fetch/fetch_counter_collection.csv $P/${R}_pmc_fetch_counter_collection.csv
 cp $O/pmc_write/write_counter_collection.csv $P/${R}_pmc_write_counter_collection.csv
 cp $O/bench_k17.json $P/${R}_bench_k17.json
-cp $O/e2e_cli.json $P/round01_e2e_cli.json
+cp $O/e2e_cli.json $P/${R}_e2e_cli.json
+cp $O/profile_mix.txt $P/${R}_profile_mix.txt
+cp $O/pmc_sq/sq_counter_collection.csv $P/${R}_pmc_sq_counter_collection.csv
 python tools/hbm_traffic.py $P/${R}_pmc_fetch_counter_collection.csv $P/${R}_pmc_write_counter_collection.csv > $P/hbm_traffic.json

@@ -11,6 +11,7 @@ cases = {
     "tandem_50pct": dict(seed=32, total_bp=200_000_000, n_records=8, pm_tandem=500, pm_dup=100),
     "dup_60pct": dict(seed=33, total_bp=200_000_000, n_records=8, pm_dup=600),
     "reads_100k_records": dict(seed=34, total_bp=100_000_000, n_records=100_000),
+    "reads_400k_records": dict(seed=34, total_bp=400_000_000, n_records=400_000),
     "n_and_lowercase": dict(seed=35, total_bp=200_000_000, n_records=8, pm_ngap=300, pm_lower=400),
 }
 k = 15
