@@ -52,7 +52,8 @@ int pk_dev_download(void *host_dst, const void *dev_src, uint64_t n_bytes, int d
 int pk_dev_mem_info(uint64_t *free_out, uint64_t *total_out, int device);
 
 /* ---- indexer: replaces gen_kmers + canonical min + process_kmers (indexer.py:130-160, 341, 162-297)
- * and the parser that feeds them (indexer.py:45-99).  k must be odd, 1 <= k <= 17 (tools.py:165-167).
+ * and the parser that feeds them (indexer.py:45-99).  k must be odd (tools.py:165-167); 1 <= k <= 17 in one table,
+ * k = 19 and 21 through pk_indexer_create_slice.
  *
  * fasta       uncompressed FASTA text (what gzip.open(...,'rt') would hand the reference)
  * table_out   4^k bytes (host); receives table[a] = min(255, #canonical k-mers with value a): the
@@ -72,6 +73,13 @@ int pk_count_release(void);
  * already live in HBM, repeated timing).  One indexer owns one 4^k table in HBM on one device. */
 typedef struct pk_indexer pk_indexer;
 int pk_indexer_create(pk_indexer **out, int k, int device);
+/* Address-range-sharded form (every shard streams the whole text and keeps the canonical k-mers of its own
+ * address range; no reduction, the shards' tables concatenate to the 4^k-byte .kin).  n_slices is a power of two; the
+ * indexer's table is bytes [slice_index, slice_index + 1) * 4^k / n_slices of the .kin image, and a slice may hold at
+ * most 2^34 addresses -- so k = 19 (256 GiB, never run by the reference: README.md:51-52) is 16 slices of 16 GiB,
+ * on one GPU after another or spread over several.  num_kmers / total_bp / records describe the whole input whatever the
+ * slice; hist256 describes the slice. */
+int pk_indexer_create_slice(pk_indexer **out, int k, int device, int slice_index, int n_slices);
 int pk_indexer_reset(pk_indexer *ix);                       /* zero the table, forget parser state  */
 /* Feed the next n_bytes of the FASTA text.  Chunks may split lines, records and k-mers anywhere.   */
 int pk_indexer_feed(pk_indexer *ix, const uint8_t *host_fasta, uint64_t n_bytes);

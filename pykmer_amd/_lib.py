@@ -28,6 +28,7 @@ _SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, _u64p, ctypes.c_int]),
     "pk_count_release": (ctypes.c_int, []),
     "pk_indexer_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
+    "pk_indexer_create_slice": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "pk_indexer_reset": (ctypes.c_int, [ctypes.c_void_p]),
     "pk_indexer_feed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
     "pk_indexer_feed_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
@@ -163,10 +164,11 @@ class DeviceBuffer:
 class Indexer:
     """One 4^k count table resident in HBM on one device (pk_indexer_*)."""
 
-    def __init__(self, k: int, device: int = 0):
+    def __init__(self, k: int, device: int = 0, slice_index: int = 0, n_slices: int = 1):
         self._h = ctypes.c_void_p()
-        self.k, self.device = k, device
-        _check(load().pk_indexer_create(ctypes.byref(self._h), k, device))
+        self.k, self.device, self.slice_index, self.n_slices = k, device, slice_index, n_slices
+        self.table_bytes = 4 ** k // n_slices
+        _check(load().pk_indexer_create_slice(ctypes.byref(self._h), k, device, slice_index, n_slices))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -204,8 +206,8 @@ class Indexer:
 
     def table_to_host(self, out: np.ndarray = None) -> np.ndarray:
         if out is None:
-            out = np.empty(4 ** self.k, dtype=np.uint8)
-        assert out.dtype == np.uint8 and out.size == 4 ** self.k and out.flags.c_contiguous
+            out = np.empty(self.table_bytes, dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.size == self.table_bytes and out.flags.c_contiguous
         _check(load().pk_indexer_table_to_host(self._h, out.ctypes.data))
         return out
 

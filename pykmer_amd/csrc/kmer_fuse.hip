@@ -60,7 +60,11 @@ __device__ __forceinline__ T wave_shr1(T v, T fill) {                   // lane 
 // NT threads, PER bases each (NT * PER = 16384 = one slot); NB = LDS room for level-1 digits; HS = hot-key slots.
 // COUNT: tally only -- `tally` counters in LDS ([n_tally], the final-bucket digit where there are two levels and
 // <= 2^14 final buckets, the level-1 digit otherwise), written out as one row per workgroup.
-template <typename KT, bool COUNT, int NT, int PER, int NB, uint32_t HS>
+// SLICED: the table holds one of 2^slice_bits address ranges; k-mers of the others are dropped, the rest are numbered
+// inside the range.  DEEP (k = 19, 21; always sliced, 1024 x 16): the k-1 bases behind a thread's first one no longer
+// fit one dword, so two are carried and the windows are cut from 96 bits; in front of a slot they come from the slots
+// before it (the chunk state's 32 bits hold 16 bases).
+template <typename KT, bool COUNT, int NT, int PER, int NB, uint32_t HS, bool SLICED, bool DEEP>
 __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict__ codes, const uint32_t *__restrict__ restarts,
                                                   const uint32_t *__restrict__ n_bases, const L2 *__restrict__ chunk_l2_state,
                                                   PartPlan pl, uint32_t n_items, uint32_t stride, void *__restrict__ out,
@@ -69,6 +73,7 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
                                                   uint32_t *__restrict__ tally_rows, unsigned long long *__restrict__ side,
                                                   unsigned long long *__restrict__ side_n, uint64_t side_cap) {
     static_assert(NT * PER == TILE && PER % 16 == 0, "one slot per workgroup");
+    static_assert(!DEEP || (PER == 16 && sizeof(KT) == 8 && SLICED), "deep windows: 64-bit k-mers, one code dword per thread, sliced table");
     constexpr int NW = PER / 16;                                          // code dwords per thread
     constexpr bool WIDE = sizeof(KT) == 8;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -87,6 +92,7 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
     const uint32_t low_mask = shift >= 32 ? 0xffffffffu : ((1u << shift) - 1u);
     const bool out16 = pl.b2 == 0;
     const KT mask = (KT)((2u * k >= sizeof(KT) * 8u) ? ~(KT)0 : (((KT)1 << (2u * k)) - 1));
+    const KT local_mask = (KT)((pl.addr_bits >= sizeof(KT) * 8u) ? ~(KT)0 : (((KT)1 << pl.addr_bits) - 1));   // SLICED: address inside the range
     const uint32_t t = threadIdx.x;
     __syncthreads();
     // items: this workgroup's slots (persistent over a contiguous range), or every stride-th slot when sampling
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
     // ISA loads and stores share one in-order counter, so a load waited for after the stores would also wait for the
     // stores to be acknowledged by HBM -- a round trip per tile with nothing else in flight.  Addresses are in range
     // for every thread whatever the slot holds; what lies past the base count is masked later.
-    struct Fetched { uint32_t nb, prev0, r_here, r_before, st_flags, st_bits, cur[NW]; };
+    struct Fetched { uint32_t nb, prev0, pprev0, r_here, r_before, st_flags, st_bits, cur[NW]; };
     auto fetch = [&](uint32_t c, Fetched &f) {
         const uint32_t *cw = codes + (uint64_t)c * SLOT_CODE_WORDS;
         const uint32_t *rw = restarts + (uint64_t)c * SLOT_RST_WORDS;
@@ -106,6 +112,7 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
 #pragma unroll
         for (int w = 0; w < NW; w++) f.cur[w] = cw[NW * t + w];
         f.prev0 = cw[t ? NW * t - 1 : 0];
+        f.pprev0 = DEEP ? cw[t > 1 ? t - 2 : 0] : 0u;
         const uint32_t ri = NW == 2 ? t : (t >> 1);
         f.r_here = rw[ri];
         f.r_before = rw[ri ? ri - 1 : 0];
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
     Fetched nxt;
     auto settle = [&]() {
         __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0); lgkmcnt / expcnt untouched
-        asm volatile("" : "+v"(nxt.nb), "+v"(nxt.prev0), "+v"(nxt.r_here), "+v"(nxt.r_before), "+v"(nxt.st_flags), "+v"(nxt.st_bits));
+        asm volatile("" : "+v"(nxt.nb), "+v"(nxt.prev0), "+v"(nxt.pprev0), "+v"(nxt.r_here), "+v"(nxt.r_before), "+v"(nxt.st_flags), "+v"(nxt.st_bits));
 #pragma unroll
         for (int w = 0; w < NW; w++) asm volatile("" : "+v"(nxt.cur[w]));
     };
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
     settle();
     for (uint32_t it = i_lo; it < i_hi; it += i_step) {
         const Fetched me = nxt;
+        const uint32_t c = item_chunk(it);
         if (it + i_step < i_hi) fetch(item_chunk(it + i_step), nxt);
         const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)me.nb);           // uniform
         if (nb == 0) { settle(); continue; }
@@ -138,12 +146,46 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
         } else {
             rbits[0] = (t & 1u) ? me.r_here : ((me.r_here << 16) | (me.r_before >> 16));
         }
-        if (t == 0) {
-            // the k-1 bases in front of the slot: the chunk's start state (newest base lowest) in stream order
-            const uint32_t len = (me.st_flags >> 8) & 0xffu;              // l2_len
-            prev0 = revpairs32(me.st_bits);
-            rbits[0] &= 0xffff0000u;
-            if (len < km1) rbits[0] |= 1u << (16u - len);                 // nothing older than those `len` bases may be used
+        uint32_t pprev0 = me.pprev0;
+        unsigned long long rb64 = 0;                                      // DEEP: restart bits of the 32 bases before the thread's (low half) and of its 16 (bits 32-47)
+        if (!DEEP) {
+            if (t == 0) {
+                // the k-1 bases in front of the slot: the chunk's start state (newest base lowest) in stream order
+                const uint32_t len = (me.st_flags >> 8) & 0xffu;          // l2_len
+                prev0 = revpairs32(me.st_bits);
+                rbits[0] &= 0xffff0000u;
+                if (len < km1) rbits[0] |= 1u << (16u - len);             // nothing older than those `len` bases may be used
+            }
+        } else {
+            uint32_t r_before = me.r_before;
+            if (t < 2) {
+                // the 32 bases in front of the slot, of which the run state says how many (len <= k-1) may be used.
+                // Up to 16 are in the state's bits; more than that are the last bases of the slots before this one.
+                const uint32_t len = (me.st_flags >> 8) & 0xffu;
+                unsigned long long before = (unsigned long long)revpairs32(me.st_bits) << 32;     // newest base at the top
+                if (len > 16u) {
+                    uint32_t have = 0;
+                    before = 0;
+                    for (uint32_t cc = c; cc > 0 && have < 32u;) {
+                        cc--;
+                        const uint32_t n_cc = n_bases[cc];
+                        const uint32_t take = min(n_cc, 32u - have);
+                        if (take == 0) continue;
+                        const uint32_t p0 = n_cc - take, d0 = p0 >> 4, sh = 2u * (p0 & 15u);
+                        const uint32_t *pw = codes + (uint64_t)cc * SLOT_CODE_WORDS;
+                        const unsigned long long w01 = ((unsigned long long)pw[min(d0 + 1u, SLOT_CODE_WORDS - 1u)] << 32) | pw[d0];
+                        const unsigned long long w2 = pw[min(d0 + 2u, SLOT_CODE_WORDS - 1u)];
+                        unsigned long long x = sh ? ((w01 >> sh) | (w2 << (64u - sh))) : w01;
+                        if (take < 32u) x &= (1ull << (2u * take)) - 1ull;
+                        before |= x << (2u * (32u - have - take));                                  // older bases lower
+                        have += take;
+                    }
+                }
+                const uint32_t va = (uint32_t)(before >> 32), vb = (uint32_t)before;              // the 16 right before the slot, the 16 before those
+                if (t == 0) { prev0 = va; pprev0 = vb; } else { pprev0 = va; }
+                r_before = (len != 0u && len < km1) ? (1u << (32u - len)) : 0u;
+            }
+            rb64 = ((((unsigned long long)me.r_here) << 32) | r_before) >> (16u * (t & 1u));
         }
         const uint32_t n_mine = live ? min((uint32_t)PER, nb - (uint32_t)PER * t) : 0u;
 
@@ -163,12 +205,35 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
         for (int w = 0; w < NW; w++) {
             const uint32_t prev = w ? cur[w ? w - 1 : 0] : prev0;
             const uint32_t cnt = n_mine > 16u * w ? min(16u, n_mine - 16u * w) : 0u;
-            // window ending at base j of this word (bit 16 + j of rbits) is void iff a restart lies among the k-1 bases after its first
-            const uint32_t hasmask = ~(smear_up(rbits[w], km1) >> 16) & ((1u << cnt) - 1u);
+            // window ending at base j of this word is void iff a restart lies among the k-1 bases after its first
+            uint32_t hasmask;
+            if (DEEP) {
+                const unsigned long long y1 = rb64 | (rb64 << 1), y2 = y1 | (y1 << 2), y3 = y2 | (y2 << 4), y4 = y3 | (y3 << 8);
+                unsigned long long acc = 0;
+                uint32_t off = 0;
+                if (km1 & 16u) { acc |= y4; off = 16; }
+                if (km1 & 8u) { acc |= y3 << off; off += 8; }
+                if (km1 & 4u) { acc |= y2 << off; off += 4; }
+                if (km1 & 2u) { acc |= y1 << off; }
+                hasmask = ~(uint32_t)(acc >> 32) & ((1u << cnt) - 1u);
+            } else {
+                hasmask = ~(smear_up(rbits[w], km1) >> 16) & ((1u << cnt) - 1u);
+            }
             const uint32_t fprev = revpairs32(prev), fcur = revpairs32(cur[w]);
             const unsigned long long fwd64 = ((unsigned long long)fprev << 32) | fcur;      // first base highest
+            const uint32_t fpp = DEEP ? revpairs32(pprev0) : 0u;
             // complemented, first base lowest, shifted once so that the window ending at base j starts at bit 2j
-            const unsigned long long rev64 = (~(((unsigned long long)cur[w] << 32) | prev)) >> (2u * (17u - k));
+            unsigned long long rev64;
+            uint32_t rev_top = 0;                                                          // DEEP: what lies above rev64 after that shift
+            if (DEEP) {
+                const uint32_t pre = 2u * (33u - k);                                       // 28 (k = 19), 24 (k = 21)
+                const unsigned long long lo = ~(((unsigned long long)prev << 32) | pprev0);
+                const uint32_t top = ~cur[w];
+                rev64 = (lo >> pre) | ((unsigned long long)top << (64u - pre));
+                rev_top = top >> pre;
+            } else {
+                rev64 = (~(((unsigned long long)cur[w] << 32) | prev)) >> (2u * (17u - k));
+            }
             const uint32_t rlo = (uint32_t)rev64, rhi = (uint32_t)(rev64 >> 32);
 #pragma unroll
             for (int j = 0; j < 16; j++) {
@@ -176,12 +241,19 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
                 if (sizeof(KT) == 4) {
                     f = (KT)__builtin_amdgcn_alignbit(fprev, fcur, 2u * (15u - j)) & mask;
                     rv = (KT)__builtin_amdgcn_alignbit(rhi, rlo, 2u * j) & mask;
-                } else {
+                } else if (!DEEP) {
                     f = (KT)(fwd64 >> (2u * (15u - j))) & mask;
                     rv = (KT)(rev64 >> (2u * j)) & mask;
+                } else {
+                    f = (KT)((fwd64 >> (2u * (15u - j))) | (j < 15 ? ((unsigned long long)fpp << (64u - 2u * (15u - j))) : 0ull)) & mask;
+                    rv = (KT)((rev64 >> (2u * j)) | (j > 0 ? ((unsigned long long)rev_top << (64u - 2u * j)) : 0ull)) & mask;
                 }
-                const KT canon = f < rv ? f : rv;                                           // indexer.py:341
-                const bool has = (hasmask >> j) & 1u;
+                KT canon = f < rv ? f : rv;                                                 // indexer.py:341
+                bool has = (hasmask >> j) & 1u;
+                if (SLICED) {
+                    has = has && (uint32_t)((unsigned long long)canon >> pl.addr_bits) == pl.slice_index;
+                    canon &= local_mask;
+                }
                 const bool e1 = canon == a1, e2 = canon == a2, e3 = canon == a3;
                 const bool miss = has & !e1 & !e2 & !e3;
                 nn += (has & e1) ? 1u : ((has & e2) ? 0x100u : ((has & e3) ? 0x10000u : 0u));
@@ -335,11 +407,32 @@ __global__ __launch_bounds__(256) void k_tally_sum(const uint32_t *__restrict__ 
 typedef ScatterLdsT<128> FuseLdsNarrow;
 constexpr size_t FUSE_LDS_NARROW = offsetof(FuseLdsNarrow, dig);
 
+// The variants: 32-bit k-mers (k <= 15) as 512 x 32, 64-bit ones (k = 17) as 1024 x 16, each for a whole table or one
+// address slice; k = 19 / 21 deep windows (always a slice).  V(COUNT, ...) names the kernel.
+#define PK_WS_NARROW(COUNT, SLICED) k_walk_sort<uint32_t, COUNT, 512, 32, 128, 512, SLICED, false>
+#define PK_WS_WIDE(COUNT, SLICED) k_walk_sort<uint64_t, COUNT, 1024, 16, 512, 1024, SLICED, false>
+#define PK_WS_DEEP(COUNT) k_walk_sort<uint64_t, COUNT, 1024, 16, 512, 1024, true, true>
+
 void fuse_set_attributes() {
-    hipFuncSetAttribute((const void *)k_walk_sort<uint32_t, false, 512, 32, 128, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSE_LDS_NARROW);
-    hipFuncSetAttribute((const void *)k_walk_sort<uint32_t, true, 512, 32, 128, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    hipFuncSetAttribute((const void *)k_walk_sort<uint64_t, false, 1024, 16, 512, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_WIDE);
-    hipFuncSetAttribute((const void *)k_walk_sort<uint64_t, true, 1024, 16, 512, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    auto set = [](const void *f, size_t bytes) { hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); };
+    set((const void *)PK_WS_NARROW(false, false), FUSE_LDS_NARROW); set((const void *)PK_WS_NARROW(false, true), FUSE_LDS_NARROW);
+    set((const void *)PK_WS_NARROW(true, false), 65536); set((const void *)PK_WS_NARROW(true, true), 65536);
+    set((const void *)PK_WS_WIDE(false, false), SCATTER_LDS_WIDE); set((const void *)PK_WS_WIDE(false, true), SCATTER_LDS_WIDE);
+    set((const void *)PK_WS_WIDE(true, false), 65536); set((const void *)PK_WS_WIDE(true, true), 65536);
+    set((const void *)PK_WS_DEEP(false), SCATTER_LDS_WIDE); set((const void *)PK_WS_DEEP(true), 65536);
+}
+
+template <bool COUNT, typename... Args>
+static void launch_ws(const PartPlan &pl, uint32_t grid, size_t lds, hipStream_t s, Args... args) {
+    const bool sliced = pl.slice_bits != 0;
+    if (pl.k > 17) hipLaunchKernelGGL((PK_WS_DEEP(COUNT)), dim3(grid), dim3(1024), lds, s, args...);
+    else if (pl.k > 15) {
+        if (sliced) hipLaunchKernelGGL((PK_WS_WIDE(COUNT, true)), dim3(grid), dim3(1024), lds, s, args...);
+        else hipLaunchKernelGGL((PK_WS_WIDE(COUNT, false)), dim3(grid), dim3(1024), lds, s, args...);
+    } else {
+        if (sliced) hipLaunchKernelGGL((PK_WS_NARROW(COUNT, true)), dim3(grid), dim3(512), lds, s, args...);
+        else hipLaunchKernelGGL((PK_WS_NARROW(COUNT, false)), dim3(grid), dim3(512), lds, s, args...);
+    }
 }
 
 // sampling launch + bucket layout.  tally_rows: COUNT_WGS x n_tally words of scratch; tally_tot: n_tally words.
@@ -351,14 +444,9 @@ void launch_provision(const uint32_t *codes, const uint32_t *restarts, const uin
     const uint32_t n_tally = pl.n_tally;
     const uint32_t tally_shift = n_tally > pl.B1 ? pl.fb_bits : pl.addr_bits - pl.b1;
     hipMemsetAsync(tally_tot, 0, (size_t)n_tally * sizeof(uint32_t), s);
-    if (pl.k <= 15)
-        hipLaunchKernelGGL((k_walk_sort<uint32_t, true, 512, 32, 128, 512>), dim3(grid), dim3(512), (size_t)n_tally * 4, s, codes, restarts, n_bases, st2,
-                           pl, n_sampled, stride, (void *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, flags, tally_shift, n_tally,
-                           tally_rows, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint64_t)0);
-    else
-        hipLaunchKernelGGL((k_walk_sort<uint64_t, true, 1024, 16, 512, 1024>), dim3(grid), dim3(1024), (size_t)n_tally * 4, s, codes, restarts, n_bases,
-                           st2, pl, n_sampled, stride, (void *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, flags, tally_shift,
-                           n_tally, tally_rows, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint64_t)0);
+    launch_ws<true>(pl, grid, (size_t)n_tally * 4, s, codes, restarts, n_bases, st2, pl, n_sampled, stride, (void *)nullptr, (uint32_t *)nullptr,
+                    (const uint32_t *)nullptr, 0u, flags, tally_shift, n_tally, tally_rows, (unsigned long long *)nullptr,
+                    (unsigned long long *)nullptr, (uint64_t)0);
     hipLaunchKernelGGL(k_tally_sum, dim3((n_tally + 255u) / 256u, grid < 16u ? 1u : 16u), dim3(256), 0, s, (const uint32_t *)tally_rows, grid, n_tally,
                        tally_tot);
     hipLaunchKernelGGL(k_provision, dim3(1), dim3(1024), 0, s, (const uint32_t *)tally_tot, n_tally, pl, n_sampled, stride, bucket_base, cursor1, cap_end,
@@ -370,12 +458,8 @@ void launch_walk_sort(const uint32_t *codes, const uint32_t *restarts, const uin
                       uint32_t *compact_base, uint32_t *wg2_start, unsigned long long *side, unsigned long long *side_n, uint64_t side_cap,
                       hipStream_t s) {
     const uint32_t dump = (uint32_t)pl.capacity1;
-    if (pl.k <= 15)
-        hipLaunchKernelGGL((k_walk_sort<uint32_t, false, 512, 32, 128, 512>), dim3(pl.n_wg0), dim3(512), FUSE_LDS_NARROW, s, codes, restarts, n_bases, st2,
-                           pl, pl.n_chunks, 1u, out1, cursor1, cap_end, dump, flags, 0u, 0u, (uint32_t *)nullptr, side, side_n, side_cap);
-    else
-        hipLaunchKernelGGL((k_walk_sort<uint64_t, false, 1024, 16, 512, 1024>), dim3(pl.n_wg0), dim3(1024), SCATTER_LDS_WIDE, s, codes, restarts, n_bases,
-                           st2, pl, pl.n_chunks, 1u, out1, cursor1, cap_end, dump, flags, 0u, 0u, (uint32_t *)nullptr, side, side_n, side_cap);
+    launch_ws<false>(pl, pl.n_wg0, pl.k > 15 ? SCATTER_LDS_WIDE : FUSE_LDS_NARROW, s, codes, restarts, n_bases, st2, pl, pl.n_chunks, 1u, out1, cursor1,
+                     cap_end, dump, flags, 0u, 0u, (uint32_t *)nullptr, side, side_n, side_cap);
     hipLaunchKernelGGL(k_level1_finish, dim3(1), dim3(1024), 0, s, (const uint32_t *)cursor1, bucket_base, cap_end, pl, bucket_end, compact_base,
                        wg2_start, (const uint32_t *)flags);
 }

@@ -476,10 +476,12 @@ __global__ __launch_bounds__(WG) void k_apply_side(const unsigned long long *__r
 }
 
 // ------------------------------------------------------------------ plan + launch sequence ------
-PartPlan make_part_plan(uint32_t k, uint64_t n_bytes) {
+PartPlan make_part_plan(uint32_t k, uint64_t n_bytes, uint32_t slice_bits, uint32_t slice_index) {
     PartPlan pl;
     pl.k = k;
-    pl.addr_bits = 2 * k;
+    pl.slice_bits = slice_bits;                            // the table holds one of 2^slice_bits equal address ranges ...
+    pl.slice_index = slice_index;                          // ... this one
+    pl.addr_bits = 2 * k - slice_bits;
     pl.fb_bits = pl.addr_bits < 16 ? pl.addr_bits : 16;
     const uint32_t bucket_bits = pl.addr_bits - pl.fb_bits;
     pl.b1 = bucket_bits <= 9 ? bucket_bits : (bucket_bits + 1) / 2;
@@ -497,7 +499,7 @@ PartPlan make_part_plan(uint32_t k, uint64_t n_bytes) {
     // bucket sizes are estimated from every 16th slot; small inputs are counted exactly
     pl.sample_stride = pl.n_chunks >= 1024u ? 16u : 1u;
     const uint64_t nfb = (uint64_t)pl.B1 * pl.B2;
-    pl.n_tally = (pl.b2 && nfb <= 16384 && k <= 15) ? (uint32_t)nfb : pl.B1;
+    pl.n_tally = (pl.b2 && nfb <= 16384 && pl.addr_bits <= 30) ? (uint32_t)nfb : pl.B1;
     // room for the buckets: the sampled estimate can reach the slot capacity (+1 per bucket from rounding up), each
     // bucket gets 12.5 % + a constant + alignment on top of it (k_provision)
     const uint64_t est1 = (uint64_t)pl.n_chunks * TILE + pl.B1, est2 = (uint64_t)pl.n_chunks * TILE + nfb;
@@ -592,6 +594,10 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     const size_t lds6 = part_addrs * 2 < 64 ? 64 : part_addrs * 2;
     int *bucket_hist = (int *)(ws + lay.bucket_hist);
     const uint32_t n_rows6 = (uint32_t)(nfb << split);
+    // bucket_hist holds one row of 256 deltas per workgroup and is sized for two workgroups per bucket
+    // (part_workspace_bytes).  A round-1 experiment with four and eight workgroups per bucket wrote rows past it -- the
+    // abort in gpurun_out/t_sp2.log (small feeds at k=11: the workspace is tiny, so the overrun left the allocation at once).
+    if ((uint64_t)n_rows6 > (uint64_t)nfb * 2) return -3;
     if (split)
         hipLaunchKernelGGL(k_bucket_count_half<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, k6_start, k6_end, pl.fb_bits, split, table8,
                            fresh ? 1u : 0u, bucket_hist, (const uint32_t *)flags);

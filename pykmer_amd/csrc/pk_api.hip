@@ -47,10 +47,17 @@ extern "C" int pk_device_count(void) {
     return n;
 }
 
-static int check_k(int k) {
-    // tools.py:165-167: k > 0 and odd.  The device path keeps the carried bases in 32 bits: k <= 17.
+// tools.py:165-167: k > 0 and odd.  One indexer holds at most 2^34 addresses (a 16 GiB table): that is all of k <= 17; beyond
+// (k = 19: 256 GiB, k = 21: 4 TiB -- README.md:51-52 marks both as never run) the address range is cut into 2^slice_bits
+// slices and an indexer counts one of them.
+static int check_k(int k, int slice_bits = 0, int slice_index = 0) {
     if (k <= 0 || (k % 2) == 0) return fail(PK_ERR_ARG, "kmer_len must be positive and odd (tools.py:165-167), got %d", k);
-    if (k > 17) return fail(PK_ERR_ARG, "kmer_len %d not supported by the device path (max 17: 4^17 = 16 GiB table)", k);
+    if (k > 21) return fail(PK_ERR_ARG, "kmer_len %d not supported by the device path (max 21)", k);
+    if (slice_bits < 0 || slice_bits > 2 * k || slice_bits > 16) return fail(PK_ERR_ARG, "bad number of address slices for kmer_len %d", k);
+    if (2 * k - slice_bits > 34)
+        return fail(PK_ERR_ARG, "kmer_len %d needs a table of 4^%d bytes; one indexer holds 2^34 (16 GiB): count it in %d address slices "
+                                "(pk_indexer_create_slice)", k, k, 1 << (2 * k - 34));
+    if (slice_index < 0 || slice_index >= (1 << slice_bits)) return fail(PK_ERR_ARG, "slice index %d outside 0..%d", slice_index, (1 << slice_bits) - 1);
     return PK_OK;
 }
 
@@ -182,7 +189,8 @@ extern "C" int pk_dev_mem_info(uint64_t *free_out, uint64_t *total_out, int devi
 // ================================================================== indexer ====================
 struct pk_indexer {
     int k = 0, device = 0;
-    uint64_t n = 0;                  // 4^k
+    int slice_bits = 0, slice_index = 0;   // the table holds addresses [slice_index, slice_index + 1) * 4^k / 2^slice_bits
+    uint64_t n = 0;                  // table bytes: 4^k / 2^slice_bits
     hipStream_t stream = nullptr;
     uint8_t *table8 = nullptr;       // the .kin image
     Carry *carry = nullptr;
@@ -244,14 +252,20 @@ extern "C" void pk_indexer_destroy(pk_indexer *ix) {
     delete ix;
 }
 
-extern "C" int pk_indexer_create(pk_indexer **out, int k, int device) {
+extern "C" int pk_indexer_create(pk_indexer **out, int k, int device) { return pk_indexer_create_slice(out, k, device, 0, 1); }
+
+extern "C" int pk_indexer_create_slice(pk_indexer **out, int k, int device, int slice_index, int n_slices) {
     if (!out) return fail(PK_ERR_ARG, "null output pointer");
     *out = nullptr;
-    int rc = check_k(k);
+    int slice_bits = 0;
+    while (slice_bits < 30 && (1 << slice_bits) < n_slices) slice_bits++;
+    if (n_slices < 1 || (1 << slice_bits) != n_slices) return fail(PK_ERR_ARG, "the number of address slices must be a power of two, got %d", n_slices);
+    int rc = check_k(k, slice_bits, slice_index);
     if (rc) return rc;
     HIPCHK(hipSetDevice(device));
     pk_indexer *ix = new pk_indexer();
-    ix->k = k; ix->device = device; ix->n = 1ULL << (2 * k);
+    ix->k = k; ix->device = device; ix->slice_bits = slice_bits; ix->slice_index = slice_index;
+    ix->n = 1ULL << (2 * k - slice_bits);
     auto bail = [&](hipError_t e, const char *what) {
         int r = fail(PK_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
         std::string keep = g_err;
@@ -328,7 +342,7 @@ static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
     rc = ensure_recs(ix, n_recs);
     if (rc) return rc;
     ix->n_recs = n_recs;
-    PartPlan pl = make_part_plan((uint32_t)ix->k, n_bytes);
+    PartPlan pl = make_part_plan((uint32_t)ix->k, n_bytes, (uint32_t)ix->slice_bits, (uint32_t)ix->slice_index);
     PartWorkspace lay;
     const size_t need = part_workspace_bytes(pl, n_bytes, &lay);
     if (need > ix->ws_cap) {

@@ -41,7 +41,8 @@ void launch_squeeze(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const
 
 // kmer_fuse.hip / kmer_part.hip -- partitioned table update
 struct PartPlan {
-    uint32_t k, addr_bits;   // 2k
+    uint32_t k, addr_bits;   // addr_bits = 2k - slice_bits: address bits of the table this indexer holds
+    uint32_t slice_bits, slice_index;   // k-mers whose top slice_bits address bits differ from slice_index are not this table's
     uint32_t fb_bits;        // address bits inside a final bucket (<= 16)
     uint32_t b1, b2, B1, B2; // level-1 / level-2 digit widths and bucket counts
     uint32_t n_chunks;       // 16 KiB FASTA chunks in this feed
@@ -60,7 +61,7 @@ struct PartWorkspace {       // byte offsets into one device allocation
         cap2_end, out1, hist2, rowoff2, out2, side, side_n, bucket_hist;
     uint64_t side_cap;
 };
-PartPlan make_part_plan(uint32_t k, uint64_t n_bytes);
+PartPlan make_part_plan(uint32_t k, uint64_t n_bytes, uint32_t slice_bits, uint32_t slice_index);
 size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace *lay);
 void part_set_attributes();
 void fuse_set_attributes();
