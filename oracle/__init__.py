@@ -38,6 +38,9 @@ def _load():
         lib.pko_count_fasta.restype = ctypes.c_int
         lib.pko_count_fasta.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p,
                                         u64p, u64p, ctypes.c_void_p, ctypes.c_uint64, u64p]
+        lib.pko_count_fasta_ex.restype = ctypes.c_int
+        lib.pko_count_fasta_ex.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p,
+                                           u64p, u64p, ctypes.c_void_p, ctypes.c_uint64, u64p, ctypes.c_void_p, ctypes.c_uint64]
         lib.pko_count_fasta_mt.restype = ctypes.c_int
         lib.pko_count_fasta_mt.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, u64p, u64p,
                                            ctypes.c_int]
@@ -73,6 +76,19 @@ def count_fasta(fasta, k: int, table: np.ndarray = None):
         cap = int(nr.value)                       # rare: re-run only to collect every record
     return {"table": table, "num_kmers": int(nk.value), "total_bp": int(bp.value),
             "records": recs[: nr.value].copy()}
+
+
+def kmer_list(fasta, k: int) -> np.ndarray:
+    """Canonical value of every valid window, in text order (u64) -- for k where the 4^k table is out of reach."""
+    lib = _load()
+    buf = np.frombuffer(fasta, dtype=np.uint8) if isinstance(fasta, (bytes, bytearray)) else np.ascontiguousarray(fasta)
+    out = np.zeros(max(1, buf.size), dtype=np.uint64)
+    nk, bp, nr = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    rc = lib.pko_count_fasta_ex(buf.ctypes.data, buf.size, k, None, ctypes.byref(nk), ctypes.byref(bp), None, 0, ctypes.byref(nr),
+                                out.ctypes.data, out.size)
+    if rc != 0:
+        raise ValueError(f"oracle rejected k={k}")
+    return out[: nk.value]
 
 
 def count_fasta_mt(fasta, k: int, threads: int, table: np.ndarray = None):

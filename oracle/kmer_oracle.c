@@ -55,9 +55,11 @@ enum { LS_START = 0, LS_HEADER = 1, LS_SEQ = 2 };
  * empty lines are skipped (indexer.py:58-59) treating '\r' and '\n' as separate terminators is
  * equivalent.
  */
-int pko_count_fasta(const uint8_t *fasta, uint64_t n_bytes, int k, uint8_t *table,
-                    uint64_t *num_kmers_out, uint64_t *total_bp_out, pko_record *recs,
-                    uint64_t recs_cap, uint64_t *n_recs_out) {
+/* `table` may be NULL when only the list is wanted (k = 19: the table would be 256 GiB); `kmers_out` (nullable) receives
+ * the canonical value of every valid window in text order, up to kmers_cap of them. */
+int pko_count_fasta_ex(const uint8_t *fasta, uint64_t n_bytes, int k, uint8_t *table,
+                       uint64_t *num_kmers_out, uint64_t *total_bp_out, pko_record *recs,
+                       uint64_t recs_cap, uint64_t *n_recs_out, uint64_t *kmers_out, uint64_t kmers_cap) {
     if (k <= 0 || (k & 1) == 0 || k > 31) return -1;            /* tools.py:165-167 */
     const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
     const int top = 2 * (k - 1);
@@ -109,7 +111,8 @@ int pko_count_fasta(const uint8_t *fasta, uint64_t n_bytes, int k, uint8_t *tabl
         if (run < k) run++;
         if (run == k && have_rec) {                              /* lines before the 1st header are dropped (indexer.py:80-82) */
             uint64_t a = fwd < rev ? fwd : rev;                  /* indexer.py:341 */
-            if (table[a] != 255) table[a]++;                     /* indexer.py:239,262 */
+            if (table && table[a] != 255) table[a]++;            /* indexer.py:239,262 */
+            if (kmers_out && num_kmers < kmers_cap) kmers_out[num_kmers] = a;
             cur.n_valid_kmers++;
             num_kmers++;
         }
@@ -124,6 +127,12 @@ int pko_count_fasta(const uint8_t *fasta, uint64_t n_bytes, int k, uint8_t *tabl
     if (total_bp_out) *total_bp_out = total_bp;
     if (n_recs_out) *n_recs_out = n_recs;
     return 0;
+}
+
+int pko_count_fasta(const uint8_t *fasta, uint64_t n_bytes, int k, uint8_t *table,
+                    uint64_t *num_kmers_out, uint64_t *total_bp_out, pko_record *recs,
+                    uint64_t recs_cap, uint64_t *n_recs_out) {
+    return pko_count_fasta_ex(fasta, n_bytes, k, table, num_kmers_out, total_bp_out, recs, recs_cap, n_recs_out, 0, 0);
 }
 
 /* tools.py:246-263.  hist[i] = #{a : table[a] == i+1}; vals = {sum, count(nonzero), min, max}. */

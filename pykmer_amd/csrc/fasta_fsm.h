@@ -94,7 +94,7 @@ __device__ __forceinline__ L2 l2_compose(const L2 &a, const L2 &b, uint32_t km1)
         uint32_t tot = alen + blen;
         if (tot > km1) tot = km1;
         f |= (a.flags & F_BRK) | (tot << 8);
-        c.bits = ((a.bits << (2u * blen)) | b.bits) & bases_mask(km1);
+        c.bits = ((blen >= 16u ? 0u : (a.bits << (2u * blen))) | b.bits) & bases_mask(km1);   // 32 bits hold the newest 16 (k = 19, 21: len runs to 20)
     }
     c.flags = f;
     return c;
@@ -352,7 +352,7 @@ __device__ __forceinline__ L2 piece_l2_clean(const uint8_t *lds, uint32_t nb, ui
         if (is_term(c)) continue;
         const uint32_t code = base_code(c);
         if (code > 3u || len >= km1) { flags |= F_BRK; open = false; }
-        else { bits |= code << (2u * len); len++; }
+        else { if (len < 16u) bits |= code << (2u * len); len++; }
     }
     if (len >= km1) flags |= F_BRK;
     L2 s; s.flags = flags | (len << 8); s.bits = bits; s.rec = 0; s.p_tail = 0;

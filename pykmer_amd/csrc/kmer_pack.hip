@@ -142,14 +142,12 @@ __device__ __forceinline__ void squeeze_clean(const uint8_t *piece, SeqWalker &w
     unsigned long long X = 0;
     {
         const unsigned long long y1 = F | (F << 1), y2 = y1 | (y1 << 2), y3 = y2 | (y2 << 4), y4 = y3 | (y3 << 8);
-        uint32_t off = 0;
-        if (km1 >= 16u) X = y4;
-        else {
-            if (km1 & 8u) { X |= y3; off = 8; }
-            if (km1 & 4u) { X |= y2 << off; off += 4; }
-            if (km1 & 2u) { X |= y1 << off; off += 2; }
-            if (km1 & 1u) { X |= F << off; }
-        }
+        uint32_t off = 0;                                                 // k - 1 <= 20 copies: 16 + 4 at most
+        if (km1 & 16u) { X |= y4; off = 16; }
+        if (km1 & 8u) { X |= y3 << off; off += 8; }
+        if (km1 & 4u) { X |= y2 << off; off += 4; }
+        if (km1 & 2u) { X |= y1 << off; off += 2; }
+        if (km1 & 1u) { X |= F << off; }
     }
     const uint32_t short_by = wk.run >= km1 ? 0u : km1 - wk.run;         // leading positions the carried run cannot complete
     const unsigned long long lead = short_by >= 64u ? ~0ull : ((1ull << short_by) - 1ull);

@@ -484,7 +484,10 @@ PartPlan make_part_plan(uint32_t k, uint64_t n_bytes, uint32_t slice_bits, uint3
     pl.addr_bits = 2 * k - slice_bits;
     pl.fb_bits = pl.addr_bits < 16 ? pl.addr_bits : 16;
     const uint32_t bucket_bits = pl.addr_bits - pl.fb_bits;
-    pl.b1 = bucket_bits <= 9 ? bucket_bits : (bucket_bits + 1) / 2;
+    // one level while its digits fit the LDS arrays of the sort kernel that runs level 1 (kmer_fuse.hip: 128 digits for
+    // 32-bit k-mers, 512 for 64-bit ones), two levels of about equal width otherwise
+    const uint32_t one_level_max = k <= 15 ? 7u : 9u;
+    pl.b1 = bucket_bits <= one_level_max ? bucket_bits : (bucket_bits + 1) / 2;
     pl.b2 = bucket_bits - pl.b1;
     pl.B1 = 1u << pl.b1;
     pl.B2 = 1u << pl.b2;
@@ -565,6 +568,7 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     uint32_t *flags = (uint32_t *)(side_n + 1);
     const uint32_t nfb = pl.B1 * pl.B2;
     const bool laid_out2 = pl.n_tally > pl.B1;
+    if (pl.B1 > (pl.k <= 15 ? 128u : 512u) || pl.B2 > 512u || pl.fb_bits > 16u) return -3;   // what the kernels' LDS arrays are sized for
     if (hipMemsetAsync(side_n, 0, 16, s) != hipSuccess) return -2;   // side-list length + flags
     launch_provision(codes, restarts, n_bases, st2, pl, stride, tally_rows, tally_tot, bucket_base, cursor1, cap_end, final_start, cursor2, cap2_end,
                      flags, s);
