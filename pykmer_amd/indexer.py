@@ -120,52 +120,91 @@ class _Input:
 TABLE_SLICE = 64 << 20          # the table leaves HBM in slices: slice i is hashed while slice i+1 crosses PCIe
 
 
-def count_file(input_file: str, kmer_len: int, device: int = 0, table_file: str = None):
+def n_address_slices(kmer_len: int) -> int:
+    """How many address slices the 4^k table is counted in: one indexer holds 2^34 addresses (16 GiB), so k <= 17 is one
+    slice, k = 19 sixteen (README.md:51-52: the reference never ran it).  PK_SLICES forces a (power-of-two) number."""
+    forced = int(os.environ.get("PK_SLICES", "0"))
+    return forced or max(1, 4 ** kmer_len >> 34)
+
+
+def count_file(input_file: str, kmer_len: int, device: int = 0, table_file: str = None, devices=None):
     """Streams one FASTA file through the GPU indexer.
 
     Returns (table, summary dict, all_records [(name, seq_len, n_valid)]).  With `table_file` the 4^k-byte
-    table is written straight into that file (tools.py:333-341: exactly 4^k bytes, no header) slice by slice as
+    table is written straight into that file (tools.py:333-341: exactly 4^k bytes, no header) piece by piece as
     it arrives, hashed on the way (summary["table_sha256"]), and `table` is the mapping of the file; otherwise
-    `table` is a host array."""
+    `table` is a host array.
+
+    A table of more than 2^34 addresses (or PK_SLICES) is counted one address slice at a time: every slice streams
+    the whole input and keeps the k-mers of its own range (option A).  `devices` spreads the slices over
+    several GPUs, one host thread each; the file is filled in address order, so the hash is still one stream."""
     import hashlib
     import queue
     import threading
+    from concurrent.futures import ThreadPoolExecutor
+    devices = tuple(devices) if devices else (device,)
+    n = 4 ** kmer_len
+    n_slices = n_address_slices(kmer_len)
+    size = n // n_slices
     source = _Input(input_file)
-    with _lib.Indexer(kmer_len, device=device) as ix:
-        for piece in source.pieces():
-            ix.feed(piece)
-        fin = ix.finish()
-        recs = ix.records(fin["n_records"])
-        fin["timings"] = ix.timings()
-        n = 4 ** kmer_len
-        if table_file is None:
-            table = ix.table_to_host()
-        else:
-            with open(table_file, "wb") as fh:
-                fh.truncate(n)
-            table = np.memmap(table_file, dtype=np.uint8, mode="r+", shape=(n,))
-            digest = hashlib.sha256()
-            todo: "queue.Queue" = queue.Queue()
+    if table_file is None:
+        table = np.empty(n, dtype=np.uint8)
+    else:
+        with open(table_file, "wb") as fh:
+            fh.truncate(n)
+        table = np.memmap(table_file, dtype=np.uint8, mode="r+", shape=(n,))
+    digest = hashlib.sha256()
+    todo: "queue.Queue" = queue.Queue(maxsize=8)
 
-            def hasher():
-                while True:
-                    part = todo.get()
-                    if part is None:
-                        return
-                    digest.update(part)                        # hashlib releases the GIL
+    def hasher():
+        while True:
+            part = todo.get()
+            if part is None:
+                return
+            digest.update(part)                                # hashlib releases the GIL
 
-            worker = threading.Thread(target=hasher)
-            worker.start()
-            try:
-                for off in range(0, n, TABLE_SLICE):
-                    part = table[off:min(n, off + TABLE_SLICE)]
-                    ix.table_slice_to_host(part, off)
+    def count_slice(s: int):
+        """Counts slice s and copies it into table[s * size : (s + 1) * size]; the first slice's pieces feed the hasher
+        as they land, later slices are hashed whole once it is their turn (the file is hashed in address order)."""
+        src = source if s == 0 else _Input(input_file)
+        with _lib.Indexer(kmer_len, device=devices[s % len(devices)], slice_index=s, n_slices=n_slices) as ix:
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()) if s else contextlib.nullcontext():
+                for piece in src.pieces():
+                    ix.feed(piece)
+            fin = ix.finish()
+            fin["records"] = ix.records(fin["n_records"]) if s == 0 else None
+            fin["timings"] = ix.timings()
+            for off in range(0, size, TABLE_SLICE):
+                part = table[s * size + off: s * size + min(size, off + TABLE_SLICE)]
+                ix.table_slice_to_host(part, off)
+                if s == 0:
                     todo.put(part)
-            finally:
-                todo.put(None)
-                worker.join()
-            table.flush()
-            fin["table_sha256"] = digest.hexdigest()
+        return fin
+
+    worker = threading.Thread(target=hasher)
+    worker.start()
+    fin, hist = None, np.zeros(256, dtype=np.uint64)
+    try:
+        with ThreadPoolExecutor(max_workers=len(devices)) as pool:
+            for s, part_fin in enumerate(pool.map(count_slice, range(n_slices))):        # results in slice order
+                hist += part_fin["hist256"]
+                if s == 0:
+                    fin = part_fin
+                else:
+                    assert part_fin["num_kmers"] == fin["num_kmers"] and part_fin["total_bp"] == fin["total_bp"]
+                    for off in range(0, size, TABLE_SLICE):
+                        todo.put(table[s * size + off: s * size + min(size, off + TABLE_SLICE)])
+    finally:
+        todo.put(None)
+        worker.join()
+    if table_file is not None:
+        table.flush()
+    fin["hist256"] = hist
+    fin["table_sha256"] = digest.hexdigest()
+    fin["n_slices"] = n_slices
+    recs = fin.pop("records")
     raw = source.names(recs)                                   # header text: byte ranges of the decompressed stream
     everything = [(nm.decode("utf-8", "replace"), int(r["seq_len"]), int(r["n_valid_kmers"])) for nm, r in zip(raw, recs)]
     return table, fin, everything
@@ -198,7 +237,8 @@ def create_fasta_index(
     import concurrent.futures
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
     input_sum = pool.submit(gen_checksum, header.input_file_path, 1 << 22)
-    table, fin, everything = count_file(input_file, kmer_len, device=device, table_file=header.index_tmp_file)
+    devices = tuple(int(d) for d in os.environ.get("PK_DEVICES", str(device)).split(",") if d != "")
+    table, fin, everything = count_file(input_file, kmer_len, device=device, table_file=header.index_tmp_file, devices=devices)
     del table
     for num, (name, seq_len, n_valid) in enumerate(everything):
         print(f"{num + 1:03d} {name} {seq_len:15,d}")           # indexer.py:136

@@ -82,3 +82,21 @@ def test_merger_cli_matches_reference_matrix(gpu, tmp_path, manifest):
     # read-back validator (indexer.py:416-444, working here)
     from pykmer_amd import indexer
     indexer.read_fasta_index("p", index_file=kins[2])
+
+
+def test_indexer_cli_counts_in_address_slices(gpu, tmp_path, manifest):
+    """The k = 19 route of the CLI (one address slice of the table at a time, slices spread over the listed devices,
+    the file filled and hashed in address order) exercised at a size with a reference golden: PK_SLICES forces four
+    slices at k = 9, PK_DEVICES names the one GPU twice.  The files must be what the reference wrote."""
+    case = manifest["indexer"]["G3_edge_k9"]
+    fa = tmp_path / case["input_file"]
+    fa.write_bytes(inputs.make_input(case["input"]))
+    env = dict(os.environ, PK_SLICES="4", PK_DEVICES="0,0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "indexer.py"), str(fa), "sample", "9"], cwd=str(tmp_path), capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    kin = f"{fa}.09.kin"
+    with open(kin + ".json") as fh:
+        meta = json.load(fh)
+    for f, v in case["expect"].items():
+        assert meta[f] == v, f
