@@ -91,11 +91,14 @@ __device__ __forceinline__ void hot_flush(HotTable<SLOTS> &H, unsigned long long
 // run[d] (this workgroup's running output offset for digit d).
 template <int NB>                  // NB = most destinations (digits) a tile is sorted into
 struct ScatterLdsT {
-    uint32_t hist[NB], off[NB], run[NB], gbase[NB];
+    // [NB .. NB + 64): one scratch digit per lane -- register slots without a record rank and park there, so the
+    // ranking and parking loops carry no branches (an LDS atomic behind a branch is waited for on the spot; sixteen
+    // of them back to back cost one round trip).  Likewise rec / dig [TILE .. TILE + 64).
+    uint32_t hist[NB + 64], off[NB + 64], run[NB], gbase[NB];
     uint32_t wsum[SC_T / 64];
     uint32_t total, pad_[3];       // records of the tile being sorted
-    uint32_t rec[TILE];
-    uint16_t dig[TILE];            // only when the digit does not fit beside the record (k = 17, level 1)
+    uint32_t rec[TILE + 64];
+    uint16_t dig[TILE + 64];       // only when the digit does not fit beside the record (k = 17, level 1)
 };
 typedef ScatterLdsT<512> ScatterLds;
 constexpr size_t SCATTER_LDS_NARROW = offsetof(ScatterLds, dig);   // 72 KiB: two workgroups per CU
@@ -124,13 +127,26 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
                                              Settle &&settle, uint32_t *claim = nullptr, const uint32_t *__restrict__ cap_end = nullptr,
                                              uint32_t dump = 0, uint32_t *overflow = nullptr) {
     static_assert(NT * PER == TILE, "tile shape");
-    uint32_t dr[PER];                                   // digit (9 bits) | rank inside the tile << 9
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t dr[PER];                                      // digit (10 bits: B <= 512, scratch digits above) | rank inside the tile << 10
+    if (PER <= 16) {
 #pragma unroll
-    for (int j = 0; j < PER; j++) {
-        dr[j] = 0;
-        if ((okm >> j) & 1u) {
-            const uint32_t dg = (uint32_t)((uint64_t)r[j] >> shift) & (B - 1u);
-            dr[j] = dg | (atomicAdd(&L.hist[dg], 1u) << 9);
+        for (int j = 0; j < PER; j++) {
+            const uint32_t dg = sizeof(RIN) == 4 ? ((uint32_t)r[j] >> shift) & (B - 1u) : (uint32_t)((uint64_t)r[j] >> shift) & (B - 1u);
+            dr[j] = ((okm >> j) & 1u) ? dg : (uint32_t)NB + lane;
+        }
+#pragma unroll
+        for (int j = 0; j < PER; j++) dr[j] |= atomicAdd(&L.hist[dr[j]], 1u) << 10;   // issued back to back, one wait for all
+    } else {
+        // 32 records per thread: keeping every digit and rank in flight at once spills (measured: 128 registers to
+        // scratch, the kernel 2.6 x slower), so each record is ranked under its own test
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            dr[j] = (uint32_t)NB + lane;
+            if ((okm >> j) & 1u) {
+                const uint32_t dg = sizeof(RIN) == 4 ? ((uint32_t)r[j] >> shift) & (B - 1u) : (uint32_t)((uint64_t)r[j] >> shift) & (B - 1u);
+                dr[j] = dg | (atomicAdd(&L.hist[dg], 1u) << 10);
+            }
         }
     }
     __syncthreads();
@@ -163,14 +179,24 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     }
     __syncthreads();
     if (n_tile == ~0u) n_tile = L.total;
+    if (PER <= 16) {
 #pragma unroll
-    for (int j = 0; j < PER; j++)
-        if ((okm >> j) & 1u) {
-            const uint32_t dg = dr[j] & 511u;
-            const uint32_t p = L.off[dg] + (dr[j] >> 9);
+        for (int j = 0; j < PER; j++) {
+            const uint32_t dg = dr[j] & 1023u;
+            const uint32_t p = ((okm >> j) & 1u) ? L.off[dg] + (dr[j] >> 10) : (uint32_t)TILE + lane;
             if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)dg; }
             else L.rec[p] = (uint32_t)r[j];
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; j++)
+            if ((okm >> j) & 1u) {
+                const uint32_t dg = dr[j] & 1023u;
+                const uint32_t p = L.off[dg] + (dr[j] >> 10);
+                if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)dg; }
+                else L.rec[p] = (uint32_t)r[j];
+            }
+    }
     if (claim && threadIdx.x < B) L.gbase[threadIdx.x] = claimed - my_off;   // sorted position p of digit d goes to p + gbase[d]
     __syncthreads();
     settle();
