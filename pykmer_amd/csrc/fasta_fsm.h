@@ -100,21 +100,22 @@ __device__ __forceinline__ L2 l2_compose(const L2 &a, const L2 &b, uint32_t km1)
     return c;
 }
 
-// Per-lane hand-off from the structure pass to the walk kernels: the lane's L2 prefix RELATIVE to its
-// chunk start (compose it behind the chunk's state to get the exact state), its incoming line state
-// and whether its piece needs the full byte machine.  16 bytes per 64-byte piece.
+// Per-lane hand-off from the structure pass to the squeeze pass: the lane's L2 prefix RELATIVE to its chunk start
+// (compose it behind the chunk's state to get the exact state), its incoming line state and whether its piece needs
+// the byte-wise machine.  8 bytes per 64-byte piece: the squeeze pass forms no k-mers, so the carried bases are left out
+// (kmer_fuse.hip takes the bases in front of a slot from the CHUNK's state).
 struct LaneState {
-    uint32_t flags;   // L2 flags | ls_in << 16 | dirty << 18
-    uint32_t bits, rec, p_tail;
+    uint32_t flags;     // L2 flags (incl. the run length) | ls_in << 16 | dirty << 18
+    uint32_t rec_tail;  // records opened before the lane, within the chunk (<= 8192) | pending blanks << 16 (<= 16384)
 };
 __device__ __forceinline__ LaneState lane_state_pack(const L2 &rel, uint32_t ls_in, bool dirty) {
     LaneState o;
     o.flags = rel.flags | (ls_in << 16) | (dirty ? (1u << 18) : 0u);
-    o.bits = rel.bits; o.rec = rel.rec; o.p_tail = (uint32_t)rel.p_tail;      // within one chunk: <= 16384
+    o.rec_tail = rel.rec | ((uint32_t)rel.p_tail << 16);
     return o;
 }
 __device__ __forceinline__ L2 lane_state_l2(const LaneState &o) {
-    L2 r; r.flags = o.flags & 0xffffu; r.bits = o.bits; r.rec = o.rec; r.p_tail = o.p_tail; return r;
+    L2 r; r.flags = o.flags & 0xffffu; r.bits = 0; r.rec = o.rec_tail & 0xffffu; r.p_tail = o.rec_tail >> 16; return r;
 }
 __device__ __forceinline__ uint32_t lane_state_ls(const LaneState &o) { return (o.flags >> 16) & 3u; }
 __device__ __forceinline__ bool lane_state_dirty(const LaneState &o) { return (o.flags >> 18) & 1u; }
