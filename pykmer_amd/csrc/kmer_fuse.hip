@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
 #pragma unroll
         for (int w = 0; w < NW; w++) f.cur[w] = cw[NW * t + w];
         f.prev0 = cw[t ? NW * t - 1 : 0];
-        f.pprev0 = DEEP ? cw[t > 1 ? t - 2 : 0] : 0u;
+        f.pprev0 = cw[NW * t > 1 ? NW * t - 2 : 0];                       // the dword before prev0: deep windows, and one more base of history for the repeat test
         const uint32_t ri = NW == 2 ? t : (t >> 1);
         f.r_here = rw[ri];
         f.r_before = rw[ri ? ri - 1 : 0];
@@ -147,6 +147,17 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
             rbits[0] = (t & 1u) ? me.r_here : ((me.r_here << 16) | (me.r_before >> 16));
         }
         uint32_t pprev0 = me.pprev0;
+        // Is the dword before `prev` usable as three more bases of history for the repeat test?  Only where it is real
+        // stream data of this slot and no restart sits on its last three bases (the restart bits a thread holds reach
+        // 16 bases back; a repeat of period 3 at k = 17 looks 18 back).
+        bool have_pp[NW];
+        if (NW == 2) {
+            have_pp[0] = t != 0 && ((me.r_before >> 13) & 7u) == 0u;
+            have_pp[NW - 1] = t != 0 && ((me.r_before >> 29) & 7u) == 0u;
+        } else {
+            const unsigned long long rb = ((((unsigned long long)me.r_here) << 32) | me.r_before) >> (16u * (t & 1u));
+            have_pp[0] = t > 1 && (((uint32_t)rb >> 13) & 7u) == 0u;
+        }
         unsigned long long rb64 = 0;                                      // DEEP: restart bits of the 32 bases before the thread's (low half) and of its 16 (bits 32-47)
         if (!DEEP) {
             if (t == 0) {
@@ -191,22 +202,22 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
 
         KT r[PER];
         uint32_t okm = 0;                                                 // bit j: r[j] is a record
-        // The lane remembers up to three distinct k-mers it has met.  A k-mer is emitted the first time it is seen;
-        // seeing it again while remembered (tandem repeats of period 1-3: the contended buckets) only bumps a
-        // counter, which goes to the workgroup's LDS table when the thread's bases end.  Either route counts each
-        // k-mer exactly once.  A new k-mer enters at a1 and pushes the others down; an entry that has collected
-        // repeats is never pushed out -- once the oldest one has, the cache stays as it is (what comes after a
-        // tandem run is emitted without being remembered).  a1, a2, a3 are pairwise distinct (an entry is only ever
-        // inserted on a miss; the initial ~0 is no k-mer), so at most one compare hits.  The three counters share
-        // one register: n1 | n2 << 8 | n3 << 16.
-        KT a1 = ~(KT)0, a2 = ~(KT)0, a3 = ~(KT)0;
-        uint32_t nn = 0;
+        // Hot keys.  Tandem repeats (poly-A/T, (AT)n, (AAG)n ...) put tens of millions of identical canonical k-mers
+        // on a handful of addresses; routed like everything else they would all land in ONE final bucket, i.e. on one
+        // CU.  A k-mer that equals the k-mer p bases earlier (p = 1, 2, 3) is therefore not emitted again but tallied:
+        // that is the case exactly when base i-s equals base i-s-p for s = 0 .. k-1, which the packed stream shows as a
+        // run of k equal-fields in  B ^ (B << 2p)  -- an AND over k shifted copies per period, for 16 bases at once,
+        // instead of a cache of recent k-mers probed at every base (round 1 / earlier this round: 19 of the 27 vector
+        // instructions per base).  The first p k-mers of a run are emitted, every later one adds to a tally for its
+        // residue class, and the tallies go to the workgroup's LDS hash table -> side list -> k_apply_side.  Either
+        // route counts each k-mer exactly once.  Where the history a thread sees (the 16 bases before its own) is too
+        // short to prove a repeat, the k-mer is simply emitted.
 #pragma unroll
         for (int w = 0; w < NW; w++) {
             const uint32_t prev = w ? cur[w ? w - 1 : 0] : prev0;
             const uint32_t cnt = n_mine > 16u * w ? min(16u, n_mine - 16u * w) : 0u;
             // window ending at base j of this word is void iff a restart lies among the k-1 bases after its first
-            uint32_t hasmask;
+            uint32_t has_x;                                                                // bit 16 + j: a restart lies among the k-1 positions before-or-at base j
             if (DEEP) {
                 const unsigned long long y1 = rb64 | (rb64 << 1), y2 = y1 | (y1 << 2), y3 = y2 | (y2 << 4), y4 = y3 | (y3 << 8);
                 unsigned long long acc = 0;
@@ -215,10 +226,11 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
                 if (km1 & 8u) { acc |= y3 << off; off += 8; }
                 if (km1 & 4u) { acc |= y2 << off; off += 4; }
                 if (km1 & 2u) { acc |= y1 << off; }
-                hasmask = ~(uint32_t)(acc >> 32) & ((1u << cnt) - 1u);
+                has_x = (uint32_t)(acc >> 16);                                              // positions 16 back .. own, like the 32-bit form
             } else {
-                hasmask = ~(smear_up(rbits[w], km1) >> 16) & ((1u << cnt) - 1u);
+                has_x = smear_up(rbits[w], km1);
             }
+            const uint32_t hasmask = ~(has_x >> 16) & ((1u << cnt) - 1u);
             const uint32_t fprev = revpairs32(prev), fcur = revpairs32(cur[w]);
             const unsigned long long fwd64 = ((unsigned long long)fprev << 32) | fcur;      // first base highest
             const uint32_t fpp = DEEP ? revpairs32(pprev0) : 0u;
@@ -235,6 +247,31 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
                 rev64 = (~(((unsigned long long)cur[w] << 32) | prev)) >> (2u * (17u - k));
             }
             const uint32_t rlo = (uint32_t)rev64, rhi = (uint32_t)(rev64 >> 32);
+            // ---- repeats of period 1-3 among this word's 16 positions (fields: base b at bits 2b, 16 before + 16 own)
+            const unsigned long long B64 = ((unsigned long long)cur[w] << 32) | prev;
+            const uint32_t pp = w ? prev0 : pprev0;                                        // the 16 bases before `prev`
+            auto repeats = [&](uint32_t p, uint32_t xr) -> uint32_t {                      // xr: restart among the k-2+p positions before-or-at
+                // field b: base b ^ base b-p; for b < p the partner is one of the last bases of `pp`
+                const unsigned long long x = B64 ^ ((B64 << (2u * p)) | (pp >> (32u - 2u * p)));
+                const unsigned long long m = ~(x | (x >> 1)) & 0x5555555555555555ull & (have_pp[w] ? ~0ull : ~((1ull << (2u * p)) - 1ull));
+                const unsigned long long a1 = m & (m << 2), a2 = a1 & (a1 << 4), a3 = a2 & (a2 << 8);
+                unsigned long long acc = ~0ull;                                             // AND of m << 2s, s = 0 .. k-1
+                uint32_t off = 0;
+                if (k & 16u) { acc &= a3 & (a3 << 16); off = 16; }
+                if (k & 8u) { acc &= a3 << (2u * off); off += 8; }
+                if (k & 4u) { acc &= a2 << (2u * off); off += 4; }
+                if (k & 2u) { acc &= a1 << (2u * off); off += 2; }
+                if (k & 1u) { acc &= m << (2u * off); }
+                uint32_t e = (uint32_t)(acc >> 32);                                         // this word's fields; gather the even bits
+                e = (e | (e >> 1)) & 0x33333333u; e = (e | (e >> 2)) & 0x0f0f0f0fu; e = (e | (e >> 4)) & 0x00ff00ffu; e = (e | (e >> 8)) & 0xffffu;
+                return e & ~xr & hasmask;
+            };
+            const uint32_t x1 = has_x | (has_x << 1), x2 = x1 | (x1 << 1), x3 = x2 | (x2 << 1);   // restart smear over k-1+p positions
+            const uint32_t d1 = repeats(1, x1 >> 16);
+            const uint32_t d2 = repeats(2, x2 >> 16) & ~d1;
+            const uint32_t d3 = repeats(3, x3 >> 16) & ~d1 & ~d2;
+            const uint32_t dup = d1 | d2 | d3;
+            uint32_t emit = hasmask & ~dup, in_slice = 0;
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 KT f, rv;
@@ -249,44 +286,38 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
                     rv = (KT)((rev64 >> (2u * j)) | (j > 0 ? ((unsigned long long)rev_top << (64u - 2u * j)) : 0ull)) & mask;
                 }
                 KT canon = f < rv ? f : rv;                                                 // indexer.py:341
-                bool has = (hasmask >> j) & 1u;
+                bool has = true;
                 if (SLICED) {
-                    has = has && (uint32_t)((unsigned long long)canon >> pl.addr_bits) == pl.slice_index;
+                    has = (uint32_t)((unsigned long long)canon >> pl.addr_bits) == pl.slice_index;
                     canon &= local_mask;
                 }
-                const bool e1 = canon == a1, e2 = canon == a2, e3 = canon == a3;
-                const bool miss = has & !e1 & !e2 & !e3;
-                nn += (has & e1) ? 1u : ((has & e2) ? 0x100u : ((has & e3) ? 0x10000u : 0u));
-                const bool push = miss & (nn < 0x10000u);                                   // the oldest entry holds no repeats: it may go
-                a3 = push ? a2 : a3;
-                a2 = push ? a1 : a2;
-                a1 = push ? canon : a1;
-                nn = push ? (nn << 8) : nn;
                 r[16 * w + j] = canon;
-                okm |= miss ? (1u << (16 * w + j)) : 0u;
+                if (SLICED) in_slice |= has ? (1u << j) : 0u;
             }
-        }
-        // ---- hot keys leave the thread.  Tandem runs span many lanes: a lane whose predecessor (the bases before)
-        // ended with the same k-mers in its cache would emit them again -- once per lane instead of once per run.
-        // Where the predecessor saw repeats at all, first occurrences it already holds become tallies too.
-        {
-            const uint32_t prev_nn = wave_shr1<uint32_t>(nn, 0u);
-            if (__any(prev_nn != 0u)) {
-                const KT p1 = wave_shr1<KT>(a1, ~(KT)0), p2 = wave_shr1<KT>(a2, ~(KT)0), p3 = wave_shr1<KT>(a3, ~(KT)0);
-                if (prev_nn != 0u) {
-#pragma unroll
-                    for (int j = 0; j < PER; j++) {
-                        if (((okm >> j) & 1u) && (r[j] == p1 || r[j] == p2 || r[j] == p3)) {
-                            okm &= ~(1u << j);
-                            if (!COUNT) hot_insert(hot, (uint64_t)r[j], 1u, side, side_n, side_cap);
-                        }
+            if (SLICED) emit &= in_slice;
+            okm |= emit << (16 * w);
+            // tallies of the repeats: one entry per period and residue class that occurs in this word (rare path)
+            if (!COUNT && __any(dup != 0u)) {
+                uint32_t left = SLICED ? (dup & in_slice) : dup;
+                while (left) {                                                             // lane-divergent: at most six rounds
+                    const uint32_t q = (uint32_t)__builtin_ctz(left);
+                    const uint32_t p = ((d1 >> q) & 1u) ? 1u : (((d2 >> q) & 1u) ? 2u : 3u);
+                    const uint32_t dp = p == 1u ? d1 : (p == 2u ? d2 : d3);
+                    uint32_t cls = 0;                                                       // q, q+p, q+2p ... while they repeat: one and the same k-mer
+                    for (uint32_t x = q; x < 16u && ((dp >> x) & 1u); x += p) cls |= 1u << x;
+                    // the k-mer at position q, cut from the packed words again (indexing the record registers by a
+                    // lane-varying q would send them all to scratch memory)
+                    unsigned long long fq = fwd64 >> (2u * (15u - q)), rq = rev64 >> (2u * q);
+                    if (DEEP) {
+                        if (q < 15u) fq |= (unsigned long long)fpp << (64u - 2u * (15u - q));
+                        if (q > 0u) rq |= (unsigned long long)rev_top << (64u - 2u * q);
                     }
+                    const KT kf = (KT)fq & mask, kr = (KT)rq & mask;
+                    KT key = kf < kr ? kf : kr;
+                    if (SLICED) key &= local_mask;
+                    hot_insert(hot, (uint64_t)key, (uint32_t)__builtin_popcount(SLICED ? (cls & in_slice) : cls), side, side_n, side_cap);
+                    left &= ~cls;
                 }
-            }
-            if (!COUNT && __any(nn != 0u)) {                                                  // this lane's own repeat tallies
-                if (nn & 0xffu) hot_insert(hot, (uint64_t)a1, nn & 0xffu, side, side_n, side_cap);
-                if (nn & 0xff00u) hot_insert(hot, (uint64_t)a2, (nn >> 8) & 0xffu, side, side_n, side_cap);
-                if (nn >> 16) hot_insert(hot, (uint64_t)a3, nn >> 16, side, side_n, side_cap);
             }
         }
         if (COUNT) {
