@@ -22,7 +22,7 @@
 //
 // Where the runs go: bucket sizes are not known before the k-mers exist.  A sampling launch of the same
 // kernel (COUNT: every 16th slot, tally only) estimates the size of every FINAL bucket (top b1+b2 address
-// bits, <= 2^14 of them; k = 17: of every level-1 bucket), k_provision lays the buckets of both levels out
+// bits, <= 2^15 of them; k = 17: of every level-1 bucket), k_provision lays the buckets of both levels out
 // with 12.5 % + a constant of slack each, and the sorts claim room for every run from per-bucket cursors.
 // A bucket that outgrows its room raises a flag (its runs go to a dump area, nothing is overwritten); every
 // later kernel of the feed then returns at once and the host repeats from here with stride 1, i.e. with
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(1024) void k_provision(const uint32_t *__restrict__
     const bool two = n_tally > B1;                          // final-bucket tallies: lay out level 2 as well
     for (uint32_t i = threadIdx.x; i < 512; i += 1024) sum1[i] = 0ull;
     __syncthreads();
-    // final buckets: each thread takes `per` consecutive ones (<= 16)
+    // final buckets: each thread takes `per` consecutive ones (<= 32)
     const uint32_t per = (n_tally + 1023u) / 1024u;
     const uint32_t lo = min(threadIdx.x * per, n_tally), hi = min(lo + per, n_tally);
     uint32_t room_sum = 0;
@@ -422,6 +422,21 @@ __global__ __launch_bounds__(1024) void k_level1_finish(const uint32_t *__restri
     const uint32_t ws = block_excl_scan_1024(g, wsum, sum_g);
     if (d < B1) { bucket_end[d] = bucket_base[d] + size; compact_base[d] = cb; wg2_start[d] = ws; }
     if (d == 0) { compact_base[B1] = sum_n; wg2_start[B1] = sum_g; }
+    // the same running count with the buckets in XCD-class order (b % 8 major): what the persistent level-2 launch walks
+    if (B1 >= 8u) {
+        const uint32_t per = B1 >> 3;
+        uint32_t g2 = 0;
+        if (d < B1) {
+            const uint32_t b = (d % per) * 8u + d / per;
+            const uint32_t size2 = min(cursor1[b], cap_end[b]) - bucket_base[b];
+            g2 = (uint32_t)(((uint64_t)size2 + pl.R2 - 1) / pl.R2);
+        }
+        uint32_t sum_g2;
+        const uint32_t ps = block_excl_scan_1024(g2, wsum, sum_g2);
+        uint32_t *pos = wg2_start + B1 + 1;
+        if (d < B1) pos[d] = ps;
+        if (d == 0) pos[B1] = sum_g2;
+    }
 }
 
 // column sums of the per-workgroup tally rows of the sampling launch
@@ -447,7 +462,7 @@ constexpr size_t FUSE_LDS_NARROW = offsetof(FuseLdsNarrow, dig);
 void fuse_set_attributes() {
     auto set = [](const void *f, size_t bytes) { hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); };
     set((const void *)PK_WS_NARROW(false, false), FUSE_LDS_NARROW); set((const void *)PK_WS_NARROW(false, true), FUSE_LDS_NARROW);
-    set((const void *)PK_WS_NARROW(true, false), 65536); set((const void *)PK_WS_NARROW(true, true), 65536);
+    set((const void *)PK_WS_NARROW(true, false), 131072); set((const void *)PK_WS_NARROW(true, true), 131072);
     set((const void *)PK_WS_WIDE(false, false), SCATTER_LDS_WIDE); set((const void *)PK_WS_WIDE(false, true), SCATTER_LDS_WIDE);
     set((const void *)PK_WS_WIDE(true, false), 65536); set((const void *)PK_WS_WIDE(true, true), 65536);
     set((const void *)PK_WS_DEEP(false), SCATTER_LDS_WIDE); set((const void *)PK_WS_DEEP(true), 65536);

@@ -98,57 +98,81 @@ __global__ __launch_bounds__(512) void k_rows2_scan(const uint32_t *__restrict__
 // CLAIM: no precomputed offsets; every tile claims room for its runs from the final buckets' cursors, inside the
 // room k_provision gave each of them (cap_end; a bucket that outgrows it raises flags[0], see part_common.h).  Where
 // a record lands inside its final bucket then depends on timing -- the bucket's contents as a multiset do not.
+// The CLAIM launch is persistent (two workgroups per CU) over work items of R2 records and XCD-affine: workgroup x
+// runs on XCD x % 8 (round-robin dispatch), and takes items of the level-1 buckets b with b % 8 == x % 8 only.  All
+// writers of one final bucket then share one L2: the partly written cache lines where one tile's run ends and the
+// next one's begins are merged there instead of travelling to HBM twice, and a bucket's cursor lives in one L2.
+// `pos` (wg2_start + B1 + 1) is the running item count over the buckets in that order (k_level1_finish).
 template <bool CLAIM>
 __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ wg2_start,
                                                    const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ bucket_end,
                                                    const uint32_t *__restrict__ rowoff, const uint32_t *__restrict__ final_start, PartPlan pl,
                                                    void *__restrict__ out, uint32_t *__restrict__ cursor, const uint32_t *__restrict__ cap_end,
-                                                   uint32_t dump, uint32_t *__restrict__ flags) {
+                                                   uint32_t dump, uint32_t *__restrict__ flags, uint32_t xcd_affine) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     ScatterLds &L = *reinterpret_cast<ScatterLds *>(smem);
-    uint32_t b, lo, hi;
     if (flags[0]) return;
-    if (!wg2_range(wg2_start, bucket_base, bucket_end, pl, b, lo, hi)) return;      // uniform per workgroup
     const uint32_t B = pl.B2, shift = pl.fb_bits;
     const uint32_t low_mask = (1u << shift) - 1u;
     if (threadIdx.x < 512) { L.hist[threadIdx.x] = 0; L.run[threadIdx.x] = 0; }
     __syncthreads();
-    if (!CLAIM && threadIdx.x < B) L.run[threadIdx.x] = final_start[(uint64_t)b * B + threadIdx.x] + rowoff[(uint64_t)blockIdx.x * B + threadIdx.x];
-    __syncthreads();
-    // 16-byte aligned windows of TILE records over [lo, hi); the first / last window are partly masked.
+    // records [lo, hi) of level-1 bucket b: 16-byte aligned windows of TILE records, the first / last partly masked.
     // The next window's loads are issued before the current tile is sorted, so they fly during its barriers.
     typedef uint32_t Quad __attribute__((ext_vector_type(4)));
-    auto fetch = [&](uint32_t win, Quad (&v)[SC_PER / 4]) {
-        const uint32_t v_hi = min(hi, win + (uint32_t)TILE);
+    auto item = [&](uint32_t b, uint32_t lo, uint32_t hi) {
+        auto fetch = [&](uint32_t win, Quad (&v)[SC_PER / 4]) {
+            const uint32_t v_hi = min(hi, win + (uint32_t)TILE);
 #pragma unroll
-        for (int j = 0; j < SC_PER / 4; j++) {
-            const uint32_t i = win + (threadIdx.x + j * SC_T) * 4u;
-            v[j] = Quad{0u, 0u, 0u, 0u};
-            if (i < v_hi) v[j] = *reinterpret_cast<const Quad *>(in + i);
+            for (int j = 0; j < SC_PER / 4; j++) {
+                const uint32_t i = win + (threadIdx.x + j * SC_T) * 4u;
+                v[j] = Quad{0u, 0u, 0u, 0u};
+                if (i < v_hi) v[j] = *reinterpret_cast<const Quad *>(in + i);
+            }
+        };
+        Quad nxt[SC_PER / 4];
+        auto settle = [&]() {                                            // see scatter_tile
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
+        };
+        fetch(lo & ~3u, nxt);
+        settle();
+        for (uint32_t win = lo & ~3u; win < hi; win += TILE) {
+            const uint32_t v_lo = max(lo, win), v_hi = min(hi, win + (uint32_t)TILE);
+            const uint32_t n_tile = v_hi - v_lo;
+            uint32_t r[SC_PER];
+            uint32_t okm = 0;
+#pragma unroll
+            for (int j = 0; j < SC_PER / 4; j++) {
+                const uint32_t i = win + (threadIdx.x + j * SC_T) * 4u;
+                const uint32_t q[4] = {nxt[j].x, nxt[j].y, nxt[j].z, nxt[j].w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) { okm |= (i + e >= v_lo && i + e < v_hi) ? (1u << (j * 4 + e)) : 0u; r[j * 4 + e] = q[e]; }
+            }
+            if (win + TILE < hi) fetch(win + TILE, nxt);
+            scatter_tile<uint32_t, false>(L, r, okm, n_tile, shift, B, low_mask, true, out, settle, CLAIM ? cursor + (uint64_t)b * B : nullptr,
+                                          CLAIM ? cap_end + (uint64_t)b * B : nullptr, dump, flags);
         }
     };
-    Quad nxt[SC_PER / 4];
-    auto settle = [&]() {                                                // see scatter_tile / k_scatter1
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
-    };
-    fetch(lo & ~3u, nxt);
-    settle();
-    for (uint32_t win = lo & ~3u; win < hi; win += TILE) {
-        const uint32_t v_lo = max(lo, win), v_hi = min(hi, win + (uint32_t)TILE);
-        const uint32_t n_tile = v_hi - v_lo;
-        uint32_t r[SC_PER];
-        uint32_t okm = 0;
-#pragma unroll
-        for (int j = 0; j < SC_PER / 4; j++) {
-            const uint32_t i = win + (threadIdx.x + j * SC_T) * 4u;
-            const uint32_t q[4] = {nxt[j].x, nxt[j].y, nxt[j].z, nxt[j].w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) { okm |= (i + e >= v_lo && i + e < v_hi) ? (1u << (j * 4 + e)) : 0u; r[j * 4 + e] = q[e]; }
-        }
-        if (win + TILE < hi) fetch(win + TILE, nxt);
-        scatter_tile<uint32_t, false>(L, r, okm, n_tile, shift, B, low_mask, true, out, settle, CLAIM ? cursor + (uint64_t)b * B : nullptr,
-                                      CLAIM ? cap_end + (uint64_t)b * B : nullptr, dump, flags);
+    if (!CLAIM) {
+        uint32_t b, lo, hi;
+        if (!wg2_range(wg2_start, bucket_base, bucket_end, pl, b, lo, hi)) return;  // uniform per workgroup
+        if (threadIdx.x < B) L.run[threadIdx.x] = final_start[(uint64_t)b * B + threadIdx.x] + rowoff[(uint64_t)blockIdx.x * B + threadIdx.x];
+        __syncthreads();
+        item(b, lo, hi);
+        return;
+    }
+    const uint32_t *pos = wg2_start + pl.B1 + 1;
+    const uint32_t per = pl.B1 >> 3;                                     // level-1 buckets per XCD class (B1 >= 16 with two levels)
+    uint32_t o_lo = 0, o_hi = pl.B1, first = blockIdx.x, step = gridDim.x;
+    if (xcd_affine) { const uint32_t c = blockIdx.x & 7u; o_lo = c * per; o_hi = o_lo + per; first = blockIdx.x >> 3; step = gridDim.x >> 3; }
+    const uint32_t w_end = pos[o_hi];
+    for (uint32_t w = pos[o_lo] + first; w < w_end; w += step) {         // uniform per workgroup
+        uint32_t a = o_lo, z = o_hi;                                     // last position with pos[a] <= w
+        while (z - a > 1) { const uint32_t m = (a + z) >> 1; if (pos[m] <= w) a = m; else z = m; }
+        const uint32_t b = (a % per) * 8u + a / per;
+        const uint64_t s = (uint64_t)bucket_base[b] + (uint64_t)(w - pos[a]) * pl.R2;
+        const uint64_t e = min(s + pl.R2, (uint64_t)bucket_end[b]);
+        item(b, (uint32_t)s, (uint32_t)e);
     }
 }
 
@@ -411,6 +435,17 @@ void k_bucket_count_half(const uint16_t *__restrict__ recs, const uint32_t *__re
     bucket_count_body<T, false>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, bucket_hist, smem, dh);
 }
 
+template <int T>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_bucket_count_half_lean(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start, const uint32_t *__restrict__ final_end,
+                              uint32_t fb_bits, uint32_t split_bits, uint8_t *__restrict__ table8, uint32_t fresh, int *__restrict__ bucket_hist,
+                              const uint32_t *__restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ int dh[256];
+    if (flags[0]) return;
+    bucket_count_body<T, true>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, bucket_hist, smem, dh);
+}
+
 // sums the per-bucket histogram rows into the running 256-bin histogram (signed deltas: two's complement adds)
 __global__ __launch_bounds__(256) void k_hist_reduce(const int *__restrict__ bucket_hist, uint32_t n_rows, unsigned long long *__restrict__ hist,
                                                      const uint32_t *__restrict__ flags) {
@@ -500,11 +535,16 @@ PartPlan make_part_plan(uint32_t k, uint64_t n_bytes, uint32_t slice_bits, uint3
     pl.slice_index = slice_index;                          // ... this one
     pl.addr_bits = 2 * k - slice_bits;
     pl.fb_bits = pl.addr_bits < 16 ? pl.addr_bits : 16;
+    // Dense tables of 32-bit k-mers (>= 1 input byte per 8 addresses, e.g. a genome at k = 15): final buckets of 2^15
+    // addresses, so that TWO bucket-count workgroups (64 KiB of counters each) share a CU and one's load / count /
+    // write-back phases hide behind the other's.  Sparse tables get there by other means (k_bucket_count_half).
+    if (k <= 15 && pl.addr_bits >= 24 && n_bytes >= (((uint64_t)1 << pl.addr_bits) >> 3)) pl.fb_bits = 15;
     const uint32_t bucket_bits = pl.addr_bits - pl.fb_bits;
     // one level while its digits fit the LDS arrays of the sort kernel that runs level 1 (kmer_fuse.hip: 128 digits for
     // 32-bit k-mers, 512 for 64-bit ones), two levels of about equal width otherwise
     const uint32_t one_level_max = k <= 15 ? 7u : 9u;
     pl.b1 = bucket_bits <= one_level_max ? bucket_bits : (bucket_bits + 1) / 2;
+    if (pl.b1 > one_level_max) pl.b1 = one_level_max;      // 15 bits = 7 + 8: level 2 sorts up to 512 ways
     pl.b2 = bucket_bits - pl.b1;
     pl.B1 = 1u << pl.b1;
     pl.B2 = 1u << pl.b2;
@@ -519,7 +559,11 @@ PartPlan make_part_plan(uint32_t k, uint64_t n_bytes, uint32_t slice_bits, uint3
     // bucket sizes are estimated from every 16th slot; small inputs are counted exactly
     pl.sample_stride = pl.n_chunks >= 1024u ? 16u : 1u;
     const uint64_t nfb = (uint64_t)pl.B1 * pl.B2;
-    pl.n_tally = (pl.b2 && nfb <= 16384 && pl.addr_bits <= 30) ? (uint32_t)nfb : pl.B1;
+    pl.n_tally = (pl.b2 && nfb <= 32768 && pl.addr_bits <= 30) ? (uint32_t)nfb : pl.B1;
+    if (pl.n_tally > pl.B1) {                              // level 2 claims its room tile by tile: small work items for a persistent grid
+        pl.R2 = 4u * TILE;
+        pl.n_wg2_max = (uint32_t)(n_bytes / pl.R2) + pl.B1 + 1;
+    }
     // room for the buckets: the sampled estimate can reach the slot capacity (+1 per bucket from rounding up), each
     // bucket gets 12.5 % + a constant + alignment on top of it (k_provision)
     const uint64_t est1 = (uint64_t)pl.n_chunks * TILE + pl.B1, est2 = (uint64_t)pl.n_chunks * TILE + nfb;
@@ -543,13 +587,13 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
     lay->compact_base = o; o += up((size_t)(pl.B1 + 1) * 4);
     lay->cursor1 = o; o += up((size_t)(pl.B1 + 1) * 4);
     lay->cap_end = o; o += up((size_t)(pl.B1 + 1) * 4);
-    lay->wg2_start = o; o += up((size_t)(pl.B1 + 1) * 4);
+    lay->wg2_start = o; o += up((size_t)(pl.B1 + 1) * 8);   // by bucket, and in XCD-class order
     lay->final_start = o; o += up((size_t)(nfb + 1) * 4);
     lay->cursor2 = o; o += up((size_t)(nfb + 1) * 4);
     lay->cap2_end = o; o += up((size_t)(nfb + 1) * 4);
     lay->out1 = o; o += up((size_t)(pl.capacity1 + TILE + 64) * (pl.b2 ? 4 : 2));      // buckets + the dump area
-    lay->hist2 = o; o += up((size_t)pl.n_wg2_max * pl.B2 * 4);
-    lay->rowoff2 = o; o += up((size_t)pl.n_wg2_max * pl.B2 * 4);
+    lay->hist2 = o; o += up(laid_out2 ? 256 : (size_t)pl.n_wg2_max * pl.B2 * 4);          // per-workgroup digit counts: only without claims
+    lay->rowoff2 = o; o += up(laid_out2 ? 256 : (size_t)pl.n_wg2_max * pl.B2 * 4);
     lay->out2 = o; o += up(!pl.b2 ? 256 : laid_out2 ? (size_t)(pl.capacity2 + TILE + 64) * 2 : (size_t)(n_bytes + 64) * 2);
     lay->side_cap = n_bytes + 16;                          // every side entry stands for >= 1 k-mer
     lay->side = o; o += up((size_t)lay->side_cap * 8);
@@ -564,6 +608,7 @@ void part_set_attributes() {
     hipFuncSetAttribute((const void *)k_scatter2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_bucket_count<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute((const void *)k_bucket_count_half<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute((const void *)k_bucket_count_half_lean<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 }
 
 // Everything behind the squeeze pass for one feed: bucket layout (sampled with `stride`; 1 = exact), the fused
@@ -596,21 +641,24 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     const uint16_t *final_recs = (const uint16_t *)out1;
     const uint32_t *k6_start = bucket_base, *k6_end = bucket_end;        // b2 == 0: the level-1 buckets are the final ones
     if (laid_out2) {
-        hipLaunchKernelGGL(k_scatter2<true>, dim3(pl.n_wg2_max), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
+        static const uint32_t xcd_affine = getenv("PK_XCD") ? (uint32_t)atoi(getenv("PK_XCD")) : 1u;
+        static const uint32_t grid2 = getenv("PK_GRID2") ? (uint32_t)atoi(getenv("PK_GRID2")) : 512u;      // 256 CUs x 2; a multiple of 8
+        hipLaunchKernelGGL(k_scatter2<true>, dim3(grid2), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
                            bucket_base, bucket_end, (const uint32_t *)nullptr, final_start, pl, out2, cursor2, (const uint32_t *)cap2_end,
-                           (uint32_t)pl.capacity2, flags);
+                           (uint32_t)pl.capacity2, flags, xcd_affine);
         final_recs = (const uint16_t *)out2; k6_start = final_start; k6_end = cursor2;   // a final bucket ends where its cursor stopped
     } else if (pl.b2) {
         hipLaunchKernelGGL(k_count2, dim3(pl.n_wg2_max), dim3(WG), 0, s, (const uint32_t *)out1, wg2_start, bucket_base, bucket_end, pl, hist2,
                            (const uint32_t *)flags);
         hipLaunchKernelGGL(k_rows2_scan, dim3(pl.B1), dim3(512), 0, s, hist2, rowoff2, wg2_start, compact_base, pl, final_start, (const uint32_t *)flags);
         hipLaunchKernelGGL(k_scatter2<false>, dim3(pl.n_wg2_max), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
-                           bucket_base, bucket_end, rowoff2, final_start, pl, out2, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, flags);
+                           bucket_base, bucket_end, rowoff2, final_start, pl, out2, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, flags, 0u);
         final_recs = (const uint16_t *)out2; k6_start = final_start; k6_end = nullptr;
     }
     if (ev_part_end) hipEventRecord(ev_part_end, s);
     // sparse tables (few records per 2^16-address bucket, k=17): 2^split workgroups per bucket, see k_bucket_count
-    const uint32_t split = (pl.fb_bits == 16 && n_bytes / nfb < 8192) ? 1u : 0u;
+    const bool sparse = pl.fb_bits == 16 && n_bytes / nfb < 8192;
+    const uint32_t split = sparse ? 1u : 0u;
     const size_t part_addrs = (size_t)1 << (pl.fb_bits - split);
     const size_t lds6 = part_addrs * 2 < 64 ? 64 : part_addrs * 2;
     int *bucket_hist = (int *)(ws + lay.bucket_hist);
@@ -619,7 +667,10 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     // (part_workspace_bytes).  A round-1 experiment with four and eight workgroups per bucket wrote rows past it -- the
     // abort in gpurun_out/t_sp2.log (small feeds at k=11: the workspace is tiny, so the overrun left the allocation at once).
     if ((uint64_t)n_rows6 > (uint64_t)nfb * 2) return -3;
-    if (split)
+    if (pl.fb_bits == 15)                                                // 64 KiB of counters: two workgroups per CU
+        hipLaunchKernelGGL(k_bucket_count_half_lean<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, k6_start, k6_end, pl.fb_bits, split, table8,
+                           fresh ? 1u : 0u, bucket_hist, (const uint32_t *)flags);
+    else if (split)
         hipLaunchKernelGGL(k_bucket_count_half<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, k6_start, k6_end, pl.fb_bits, split, table8,
                            fresh ? 1u : 0u, bucket_hist, (const uint32_t *)flags);
     else

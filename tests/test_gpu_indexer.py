@@ -158,6 +158,31 @@ def test_histogram_kept_across_dense_and_sparse_feeds(gpu, k):
                 assert fin["num_kmers"] == want["num_kmers"]
 
 
+@pytest.mark.parametrize("k,n_bp", [(13, 10_000_000)])
+def test_dense_feeds_use_half_size_buckets(gpu, k, n_bp):
+    """A feed with >= 1 byte per 8 table addresses takes 2^15-address final buckets (two bucket-count workgroups per
+    CU, make_part_plan); smaller feeds on the same table take the 2^16 ones.  Fresh and on top of earlier feeds."""
+    import synth
+    dense, _ = synth.generate(21, n_bp, 3, pm_dup=150, pm_tandem=150)
+    small, _ = synth.generate(22, 40_000, 2, pm_tandem=200)
+    for order in ([dense], [small, dense, small], [dense, dense]):
+        whole = np.concatenate(order)
+        want = oracle.count_fasta(whole, k)
+        with gpu.Indexer(k) as ix:
+            for piece in order:
+                ix.feed(piece)
+            fin = ix.finish()
+            assert fin["num_kmers"] == want["num_kmers"]
+            assert np.array_equal(ix.table_to_host(), want["table"])
+            assert np.array_equal(fin["hist256"][1:], oracle.table_stats(want["table"])[0])
+    # the same through an address slice: 13 bits of buckets over a 2^24-address range
+    with gpu.Indexer(k, slice_index=2, n_slices=4) as ix:
+        ix.feed(dense)
+        ix.finish()
+        quarter = 4 ** k // 4
+        assert np.array_equal(ix.table_to_host(), oracle.count_fasta(dense, k)["table"][2 * quarter: 3 * quarter])
+
+
 def test_control_bytes_inside_sequence_lines(gpu):
     """Bytes below 0x21 other than \\n / \\r (NUL, \\x01, tab, VT, FS..US, space) and DEL inside sequence
     text: blanks are stripped at line ends and map to None inside, the rest are plain non-bases.  Such
