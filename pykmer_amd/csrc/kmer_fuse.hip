@@ -357,12 +357,25 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *w
     return pre + inc - v;
 }
 
-__device__ __forceinline__ uint32_t room_for(unsigned long long h, uint32_t n_chunks, uint32_t n_sampled, uint32_t stride, uint32_t slack) {
+// room for a bucket whose sampled tally is h: the scaled estimate + 12.5 % + slack (stride 1: h itself, exact or an over-count)
+__device__ __forceinline__ uint32_t room_for(unsigned long long h, double scale, uint32_t stride, uint32_t slack) {
     if (stride == 1) return (uint32_t)h;
-    const unsigned long long est = (h * n_chunks + n_sampled - 1) / n_sampled;
+    const unsigned long long est = (unsigned long long)((double)h * scale) + 1ull;       // h < 2^32, scale <= 16: exact enough, and deterministic
     return (uint32_t)(est + est / 8 + slack);
 }
 
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+    return v;
+}
+
+// Final buckets are laid out by waves: wave w owns the tallies [w * seg, (w + 1) * seg), seg a multiple of 64, and
+// walks them in rows of 64 (coalesced loads, all issued up front; one wave scan per row; no barrier until the sixteen
+// wave totals meet).  A first version gave every thread 32 consecutive tallies in a loop: 94 us at 2^15 buckets, nearly
+// all of it load latency, one after the other.
+constexpr int PROV_ROWS = 32;                               // 16 waves x 32 rows x 64 = 2^15 final buckets at most
 __global__ __launch_bounds__(1024) void k_provision(const uint32_t *__restrict__ tot, uint32_t n_tally, PartPlan pl, uint32_t n_sampled,
                                                     uint32_t stride, uint32_t *__restrict__ bucket_base, uint32_t *__restrict__ cursor1,
                                                     uint32_t *__restrict__ cap_end, uint32_t *__restrict__ final_start,
@@ -371,31 +384,56 @@ __global__ __launch_bounds__(1024) void k_provision(const uint32_t *__restrict__
     __shared__ unsigned long long sum1[512];                // sampled tallies per level-1 bucket
     const uint32_t B1 = pl.B1;
     const bool two = n_tally > B1;                          // final-bucket tallies: lay out level 2 as well
+    const double scale = (double)pl.n_chunks / (double)n_sampled;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     for (uint32_t i = threadIdx.x; i < 512; i += 1024) sum1[i] = 0ull;
     __syncthreads();
-    // final buckets: each thread takes `per` consecutive ones (<= 32)
-    const uint32_t per = (n_tally + 1023u) / 1024u;
-    const uint32_t lo = min(threadIdx.x * per, n_tally), hi = min(lo + per, n_tally);
-    uint32_t room_sum = 0;
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t h = tot[i];
-        if (two) room_sum += (room_for(h, pl.n_chunks, n_sampled, stride, 2048u) + 7u) & ~7u;   // 16-bit records: starts stay 16-byte aligned
-        if (h) atomicAdd(&sum1[two ? (i >> pl.b2) : i], (unsigned long long)h);
+    const uint32_t seg = (((n_tally + 15u) / 16u) + 63u) & ~63u;
+    const uint32_t rows = seg / 64u;                        // <= PROV_ROWS (launch_provision checks)
+    uint32_t h[PROV_ROWS], room[PROV_ROWS];
+#pragma unroll
+    for (int r = 0; r < PROV_ROWS; r++) {
+        const uint32_t i = w * seg + (uint32_t)r * 64u + lane;
+        h[r] = ((uint32_t)r < rows && i < n_tally) ? tot[i] : 0u;
+    }
+    uint32_t wave_total = 0;                                // uniform
+#pragma unroll
+    for (int r = 0; r < PROV_ROWS; r++) {
+        room[r] = 0;
+        if ((uint32_t)r < rows) {                           // uniform
+            const uint32_t i = w * seg + (uint32_t)r * 64u + lane;
+            const bool in = i < n_tally;
+            if (in && h[r]) atomicAdd(&sum1[two ? (i >> pl.b2) : i], (unsigned long long)h[r]);
+            if (two) {
+                const uint32_t mine = in ? ((room_for(h[r], scale, stride, 2048u) + 7u) & ~7u) : 0u;   // 16-bit records: starts stay 16-byte aligned
+                const uint32_t inc = wave_incl_scan_u32(mine);
+                room[r] = mine;
+                h[r] = wave_total + inc - mine;            // start inside the wave's stretch
+                wave_total += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            }
+        }
     }
     if (two) {
-        uint32_t total2;
-        uint32_t a = block_excl_scan_1024(room_sum, wsum, total2);
-        for (uint32_t i = lo; i < hi; i++) {
-            const uint32_t room = (room_for(tot[i], pl.n_chunks, n_sampled, stride, 2048u) + 7u) & ~7u;
-            final_start[i] = a; cursor2[i] = a; cap2_end[i] = a + room;
-            a += room;
+        if (lane == 0) wsum[w] = wave_total;
+        __syncthreads();
+        uint32_t pre = 0, total2 = 0;
+        for (uint32_t i = 0; i < 16; i++) { if (i < w) pre += wsum[i]; total2 += wsum[i]; }
+#pragma unroll
+        for (int r = 0; r < PROV_ROWS; r++) {
+            const uint32_t i = w * seg + (uint32_t)r * 64u + lane;
+            if ((uint32_t)r < rows && i < n_tally) {
+                const uint32_t a = pre + h[r];
+                final_start[i] = a; cursor2[i] = a; cap2_end[i] = a + room[r];
+            }
         }
-        if (threadIdx.x == 1023) final_start[n_tally] = a;
-        if (threadIdx.x == 0 && (uint64_t)total2 > pl.capacity2) flags[0] = 1u;
+        if (threadIdx.x == 0) {
+            final_start[n_tally] = total2;
+            if ((uint64_t)total2 > pl.capacity2) flags[0] = 1u;
+        }
     }
     __syncthreads();
     uint32_t room1 = 0;
-    if (threadIdx.x < B1) room1 = (room_for(sum1[threadIdx.x], pl.n_chunks, n_sampled, stride, 4096u) + 3u) & ~3u;   // 16-byte aligned starts
+    if (threadIdx.x < B1) room1 = (room_for(sum1[threadIdx.x], scale, stride, 4096u) + 3u) & ~3u;   // 16-byte aligned starts
     uint32_t total1;
     const uint32_t base = block_excl_scan_1024(room1, wsum, total1);
     if (threadIdx.x < B1) { bucket_base[threadIdx.x] = base; cursor1[threadIdx.x] = base; cap_end[threadIdx.x] = base + room1; }

@@ -128,26 +128,23 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
                                              uint32_t dump = 0, uint32_t *overflow = nullptr) {
     static_assert(NT * PER == TILE, "tile shape");
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t dr[PER];                                      // digit (10 bits: B <= 512, scratch digits above) | rank inside the tile << 10
+    const uint32_t dbits = (uint32_t)__builtin_ctz(B);
+    auto digit_of = [&](const RIN &x) -> uint32_t {
+        return sizeof(RIN) == 4 ? __builtin_amdgcn_ubfe((uint32_t)x, shift, dbits) : (uint32_t)((uint64_t)x >> shift) & (B - 1u);
+    };
+    uint32_t dr[PER <= 16 ? PER : 1];                      // PER <= 16: digit (10 bits: B <= 512, scratch digits above) | rank inside the tile << 10
     if (PER <= 16) {
 #pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const uint32_t dg = sizeof(RIN) == 4 ? ((uint32_t)r[j] >> shift) & (B - 1u) : (uint32_t)((uint64_t)r[j] >> shift) & (B - 1u);
-            dr[j] = ((okm >> j) & 1u) ? dg : (uint32_t)NB + lane;
-        }
+        for (int j = 0; j < PER; j++) dr[j] = ((okm >> j) & 1u) ? digit_of(r[j]) : (uint32_t)NB + lane;
 #pragma unroll
         for (int j = 0; j < PER; j++) dr[j] |= atomicAdd(&L.hist[dr[j]], 1u) << 10;   // issued back to back, one wait for all
     } else {
         // 32 records per thread: keeping every digit and rank in flight at once spills (measured: 128 registers to
-        // scratch, the kernel 2.6 x slower), so each record is ranked under its own test
+        // scratch, the kernel 2.6 x slower).  Here the digits are only counted (adds that return nothing), and a record
+        // finds its place when it is parked: a second add, on the digit's running offset, hands out the positions.
 #pragma unroll
-        for (int j = 0; j < PER; j++) {
-            dr[j] = (uint32_t)NB + lane;
-            if ((okm >> j) & 1u) {
-                const uint32_t dg = sizeof(RIN) == 4 ? ((uint32_t)r[j] >> shift) & (B - 1u) : (uint32_t)((uint64_t)r[j] >> shift) & (B - 1u);
-                dr[j] = dg | (atomicAdd(&L.hist[dg], 1u) << 10);
-            }
-        }
+        for (int j = 0; j < PER; j++)
+            if ((okm >> j) & 1u) __hip_atomic_fetch_add(&L.hist[digit_of(r[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     // exclusive scan of hist[0..B) by the first B threads (B <= NB <= NT)
@@ -191,8 +188,8 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
 #pragma unroll
         for (int j = 0; j < PER; j++)
             if ((okm >> j) & 1u) {
-                const uint32_t dg = dr[j] & 1023u;
-                const uint32_t p = L.off[dg] + (dr[j] >> 10);
+                const uint32_t dg = digit_of(r[j]);
+                const uint32_t p = atomicAdd(&L.off[dg], 1u);                    // off[d] ends at the start of run d + 1; gbase keeps the starts
                 if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)dg; }
                 else L.rec[p] = (uint32_t)r[j];
             }
@@ -221,22 +218,18 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
             }
         }
     } else {
-        // 32-bit records: neighbours in sorted order leave as one 8-byte store when they share a run
+        // 32-bit records, one per lane and store: 64 consecutive sorted positions are 64 consecutive dwords of a run (or of
+        // two).  The parked record still carries what it had above `low_mask` (narrow: its digit; wide: nothing) -- every
+        // reader of 32-bit records masks for itself.  (Storing neighbours pairwise as 8 bytes, as round 1 did, halves the
+        // store instructions but costs 15 vector instructions per record against 5 here, and the kernel is issue-bound.)
         uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
 #pragma unroll
-        for (int j = 0; j < PER / 2; j++) {
-            const uint32_t p = 2u * (threadIdx.x + j * NT);
+        for (int j = 0; j < PER; j++) {
+            const uint32_t p = threadIdx.x + (uint32_t)j * NT;
             if (p < n_tile) {
-                const uint32_t r0 = L.rec[p], r1 = p + 1 < n_tile ? L.rec[p + 1] : 0u;
-                const uint32_t d0 = WIDE ? L.dig[p] : (r0 >> shift) & (B - 1u);
-                const uint32_t d1 = p + 1 < n_tile ? (WIDE ? (uint32_t)L.dig[p + 1] : (r1 >> shift) & (B - 1u)) : ~0u;
-                const uint32_t dst0 = p + L.gbase[d0];
-                if (d0 == d1 && (dst0 & 1u) == 0u) {
-                    *reinterpret_cast<uint2 *>(o32 + dst0) = make_uint2(r0 & low_mask, r1 & low_mask);
-                } else {
-                    o32[dst0] = r0 & low_mask;
-                    if (p + 1 < n_tile) o32[p + 1 + L.gbase[d1]] = r1 & low_mask;
-                }
+                const uint32_t r0 = L.rec[p];
+                const uint32_t d0 = WIDE ? (uint32_t)L.dig[p] : __builtin_amdgcn_ubfe(r0, shift, dbits);
+                o32[p + L.gbase[d0]] = r0;
             }
         }
     }
