@@ -140,17 +140,23 @@ __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ 
             const uint32_t v_lo = max(lo, win), v_hi = min(hi, win + (uint32_t)TILE);
             const uint32_t n_tile = v_hi - v_lo;
             uint32_t r[SC_PER];
+#pragma unroll
+            for (int j = 0; j < SC_PER / 4; j++) { r[j * 4] = nxt[j].x; r[j * 4 + 1] = nxt[j].y; r[j * 4 + 2] = nxt[j].z; r[j * 4 + 3] = nxt[j].w; }
+            const bool full = v_lo == win && n_tile == (uint32_t)TILE;   // uniform; nearly every tile: items start 16-byte aligned
             uint32_t okm = 0;
+            if (!full) {
 #pragma unroll
-            for (int j = 0; j < SC_PER / 4; j++) {
-                const uint32_t i = win + (threadIdx.x + j * SC_T) * 4u;
-                const uint32_t q[4] = {nxt[j].x, nxt[j].y, nxt[j].z, nxt[j].w};
+                for (int j = 0; j < SC_PER / 4; j++) {
+                    const uint32_t i = win + (threadIdx.x + j * SC_T) * 4u;
 #pragma unroll
-                for (int e = 0; e < 4; e++) { okm |= (i + e >= v_lo && i + e < v_hi) ? (1u << (j * 4 + e)) : 0u; r[j * 4 + e] = q[e]; }
+                    for (int e = 0; e < 4; e++) okm |= (i + e >= v_lo && i + e < v_hi) ? (1u << (j * 4 + e)) : 0u;
+                }
             }
             if (win + TILE < hi) fetch(win + TILE, nxt);
-            scatter_tile<uint32_t, false>(L, r, okm, n_tile, shift, B, low_mask, true, out, settle, CLAIM ? cursor + (uint64_t)b * B : nullptr,
-                                          CLAIM ? cap_end + (uint64_t)b * B : nullptr, dump, flags);
+            uint32_t *cl = CLAIM ? cursor + (uint64_t)b * B : nullptr;
+            const uint32_t *ce = CLAIM ? cap_end + (uint64_t)b * B : nullptr;
+            if (full) scatter_tile<uint32_t, false, SC_T, SC_PER, 512, true>(L, r, 0u, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
+            else scatter_tile<uint32_t, false>(L, r, okm, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
         }
     };
     if (!CLAIM) {

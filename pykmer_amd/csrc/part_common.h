@@ -121,7 +121,14 @@ constexpr size_t SCATTER_LDS_WIDE = sizeof(ScatterLds);            // 104 KiB
 // and leaves the stores in flight through the next tile's ranking and parking.
 // NT threads sort PER records each (NT * PER = TILE); bit j of `okm` tells whether r[j] holds a record (one
 // register instead of PER lane masks: 32 booleans do not fit the scalar register file).
-template <typename RIN, bool WIDE, int NT = SC_T, int PER = SC_PER, int NB = 512, class Settle>
+// FULL: every register slot holds a record (okm is not looked at).
+//
+// Ranking is count-then-claim: the digits are first only counted (LDS adds that return nothing), and after the scan
+// a record finds its place when it is parked -- a second add, on its digit's running offset, hands out the positions
+// (off[d] ends at the start of run d + 1; gbase keeps the starts).  Round 1 ranked with one returning add and kept
+// digit and rank of every record in a register until the scan was done: 16 or 32 more live registers and three to
+// four more vector instructions per record, in kernels that are bound by instruction issue.
+template <typename RIN, bool WIDE, int NT = SC_T, int PER = SC_PER, int NB = 512, bool FULL = false, class Settle>
 __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[PER], uint32_t okm, uint32_t n_tile,
                                              uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out,
                                              Settle &&settle, uint32_t *claim = nullptr, const uint32_t *__restrict__ cap_end = nullptr,
@@ -132,19 +139,19 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     auto digit_of = [&](const RIN &x) -> uint32_t {
         return sizeof(RIN) == 4 ? __builtin_amdgcn_ubfe((uint32_t)x, shift, dbits) : (uint32_t)((uint64_t)x >> shift) & (B - 1u);
     };
-    uint32_t dr[PER <= 16 ? PER : 1];                      // PER <= 16: digit (10 bits: B <= 512, scratch digits above) | rank inside the tile << 10
+    uint32_t dg[PER <= 16 ? PER : 1];                      // PER <= 16: the digit, or this lane's scratch digit for an empty slot
     if (PER <= 16) {
+        // branch-free: an LDS operation behind a branch is waited for on the spot, sixteen back to back cost one round trip
 #pragma unroll
-        for (int j = 0; j < PER; j++) dr[j] = ((okm >> j) & 1u) ? digit_of(r[j]) : (uint32_t)NB + lane;
+        for (int j = 0; j < PER; j++) dg[j] = (FULL || ((okm >> j) & 1u)) ? digit_of(r[j]) : (uint32_t)NB + lane;
 #pragma unroll
-        for (int j = 0; j < PER; j++) dr[j] |= atomicAdd(&L.hist[dr[j]], 1u) << 10;   // issued back to back, one wait for all
+        for (int j = 0; j < PER; j++) __hip_atomic_fetch_add(&L.hist[dg[j]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!FULL && threadIdx.x < 64u) L.off[NB + threadIdx.x] = (uint32_t)TILE + threadIdx.x;   // where empty slots park (adds of zero)
     } else {
-        // 32 records per thread: keeping every digit and rank in flight at once spills (measured: 128 registers to
-        // scratch, the kernel 2.6 x slower).  Here the digits are only counted (adds that return nothing), and a record
-        // finds its place when it is parked: a second add, on the digit's running offset, hands out the positions.
+        // 32 records per thread: every record under its own test (32 digits in registers spill)
 #pragma unroll
         for (int j = 0; j < PER; j++)
-            if ((okm >> j) & 1u) __hip_atomic_fetch_add(&L.hist[digit_of(r[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (FULL || ((okm >> j) & 1u)) __hip_atomic_fetch_add(&L.hist[digit_of(r[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     // exclusive scan of hist[0..B) by the first B threads (B <= NB <= NT)
@@ -179,18 +186,17 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     if (PER <= 16) {
 #pragma unroll
         for (int j = 0; j < PER; j++) {
-            const uint32_t dg = dr[j] & 1023u;
-            const uint32_t p = ((okm >> j) & 1u) ? L.off[dg] + (dr[j] >> 10) : (uint32_t)TILE + lane;
-            if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)dg; }
+            const uint32_t p = atomicAdd(&L.off[dg[j]], (FULL || ((okm >> j) & 1u)) ? 1u : 0u);
+            if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)dg[j]; }
             else L.rec[p] = (uint32_t)r[j];
         }
     } else {
 #pragma unroll
         for (int j = 0; j < PER; j++)
-            if ((okm >> j) & 1u) {
-                const uint32_t dg = digit_of(r[j]);
-                const uint32_t p = atomicAdd(&L.off[dg], 1u);                    // off[d] ends at the start of run d + 1; gbase keeps the starts
-                if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)dg; }
+            if (FULL || ((okm >> j) & 1u)) {
+                const uint32_t d = digit_of(r[j]);
+                const uint32_t p = atomicAdd(&L.off[d], 1u);
+                if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)d; }
                 else L.rec[p] = (uint32_t)r[j];
             }
     }
@@ -198,23 +204,15 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     __syncthreads();
     settle();
     if (out16) {
-        // 16-bit records: each thread takes pairs of neighbours in sorted order and writes them as one
-        // dword when they fall in the same run and the destination is even (the common case)
+        // 16-bit records, one per lane and store (64 consecutive sorted positions = 128 contiguous bytes of a run, or of two)
         uint16_t *o16 = reinterpret_cast<uint16_t *>(out);
 #pragma unroll
-        for (int j = 0; j < PER / 2; j++) {
-            const uint32_t p = 2u * (threadIdx.x + j * NT);
+        for (int j = 0; j < PER; j++) {
+            const uint32_t p = threadIdx.x + (uint32_t)j * NT;
             if (p < n_tile) {
-                const uint32_t r0 = L.rec[p], r1 = p + 1 < n_tile ? L.rec[p + 1] : 0u;
-                const uint32_t d0 = WIDE ? L.dig[p] : (r0 >> shift) & (B - 1u);
-                const uint32_t d1 = p + 1 < n_tile ? (WIDE ? (uint32_t)L.dig[p + 1] : (r1 >> shift) & (B - 1u)) : ~0u;
-                const uint32_t dst0 = p + L.gbase[d0];
-                if (d0 == d1 && (dst0 & 1u) == 0u) {
-                    *reinterpret_cast<uint32_t *>(o16 + dst0) = (r0 & low_mask) | ((r1 & low_mask) << 16);
-                } else {
-                    o16[dst0] = (uint16_t)(r0 & low_mask);
-                    if (p + 1 < n_tile) o16[p + 1 + L.gbase[d1]] = (uint16_t)(r1 & low_mask);
-                }
+                const uint32_t r0 = L.rec[p];
+                const uint32_t d0 = WIDE ? (uint32_t)L.dig[p] : __builtin_amdgcn_ubfe(r0, shift, dbits);
+                o16[p + L.gbase[d0]] = (uint16_t)(r0 & low_mask);
             }
         }
     } else {
