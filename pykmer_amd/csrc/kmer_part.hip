@@ -103,8 +103,10 @@ __global__ __launch_bounds__(512) void k_rows2_scan(const uint32_t *__restrict__
 // writers of one final bucket then share one L2: the partly written cache lines where one tile's run ends and the
 // next one's begins are merged there instead of travelling to HBM twice, and a bucket's cursor lives in one L2.
 // `pos` (wg2_start + B1 + 1) is the running item count over the buckets in that order (k_level1_finish).
-template <bool CLAIM>
-__global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ wg2_start,
+// NT threads x PER records = one tile.  The CLAIM launch runs as 512 x 32: two workgroups share a CU (72 KiB of LDS and
+// 128 registers each), so one sorts while the other waits at a barrier or for its stores.
+template <bool CLAIM, int NT, int PER>
+__global__ __launch_bounds__(NT, 4) void k_scatter2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ wg2_start,
                                                    const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ bucket_end,
                                                    const uint32_t *__restrict__ rowoff, const uint32_t *__restrict__ final_start, PartPlan pl,
                                                    void *__restrict__ out, uint32_t *__restrict__ cursor, const uint32_t *__restrict__ cap_end,
@@ -114,40 +116,41 @@ __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ 
     if (flags[0]) return;
     const uint32_t B = pl.B2, shift = pl.fb_bits;
     const uint32_t low_mask = (1u << shift) - 1u;
-    if (threadIdx.x < 512) { L.hist[threadIdx.x] = 0; L.run[threadIdx.x] = 0; }
+    for (uint32_t i = threadIdx.x; i < 512; i += NT) { L.hist[i] = 0; L.run[i] = 0; }
     __syncthreads();
     // records [lo, hi) of level-1 bucket b: 16-byte aligned windows of TILE records, the first / last partly masked.
     // The next window's loads are issued before the current tile is sorted, so they fly during its barriers.
     typedef uint32_t Quad __attribute__((ext_vector_type(4)));
     auto item = [&](uint32_t b, uint32_t lo, uint32_t hi) {
-        auto fetch = [&](uint32_t win, Quad (&v)[SC_PER / 4]) {
+        auto fetch = [&](uint32_t win, Quad (&v)[PER / 4]) {
             const uint32_t v_hi = min(hi, win + (uint32_t)TILE);
 #pragma unroll
-            for (int j = 0; j < SC_PER / 4; j++) {
-                const uint32_t i = win + (threadIdx.x + j * SC_T) * 4u;
+            for (int j = 0; j < PER / 4; j++) {
+                const uint32_t i = win + (threadIdx.x + j * NT) * 4u;
                 v[j] = Quad{0u, 0u, 0u, 0u};
                 if (i < v_hi) v[j] = *reinterpret_cast<const Quad *>(in + i);
             }
         };
-        Quad nxt[SC_PER / 4];
+        Quad nxt[PER / 4];
         auto settle = [&]() {                                            // see scatter_tile
             __builtin_amdgcn_s_waitcnt(0x0F70);
-            asm volatile("" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]));
+#pragma unroll
+            for (int j = 0; j < PER / 4; j++) asm volatile("" : "+v"(nxt[j]));
         };
         fetch(lo & ~3u, nxt);
         settle();
         for (uint32_t win = lo & ~3u; win < hi; win += TILE) {
             const uint32_t v_lo = max(lo, win), v_hi = min(hi, win + (uint32_t)TILE);
             const uint32_t n_tile = v_hi - v_lo;
-            uint32_t r[SC_PER];
+            uint32_t r[PER];
 #pragma unroll
-            for (int j = 0; j < SC_PER / 4; j++) { r[j * 4] = nxt[j].x; r[j * 4 + 1] = nxt[j].y; r[j * 4 + 2] = nxt[j].z; r[j * 4 + 3] = nxt[j].w; }
+            for (int j = 0; j < PER / 4; j++) { r[j * 4] = nxt[j].x; r[j * 4 + 1] = nxt[j].y; r[j * 4 + 2] = nxt[j].z; r[j * 4 + 3] = nxt[j].w; }
             const bool full = v_lo == win && n_tile == (uint32_t)TILE;   // uniform; nearly every tile: items start 16-byte aligned
             uint32_t okm = 0;
             if (!full) {
 #pragma unroll
-                for (int j = 0; j < SC_PER / 4; j++) {
-                    const uint32_t i = win + (threadIdx.x + j * SC_T) * 4u;
+                for (int j = 0; j < PER / 4; j++) {
+                    const uint32_t i = win + (threadIdx.x + j * NT) * 4u;
 #pragma unroll
                     for (int e = 0; e < 4; e++) okm |= (i + e >= v_lo && i + e < v_hi) ? (1u << (j * 4 + e)) : 0u;
                 }
@@ -155,8 +158,8 @@ __global__ __launch_bounds__(SC_T) void k_scatter2(const uint32_t *__restrict__ 
             if (win + TILE < hi) fetch(win + TILE, nxt);
             uint32_t *cl = CLAIM ? cursor + (uint64_t)b * B : nullptr;
             const uint32_t *ce = CLAIM ? cap_end + (uint64_t)b * B : nullptr;
-            if (full) scatter_tile<uint32_t, false, SC_T, SC_PER, 512, true>(L, r, 0u, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
-            else scatter_tile<uint32_t, false>(L, r, okm, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
+            if (full) scatter_tile<uint32_t, false, NT, PER, 512, true>(L, r, 0u, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
+            else scatter_tile<uint32_t, false, NT, PER, 512, false>(L, r, okm, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
         }
     };
     if (!CLAIM) {
@@ -211,16 +214,35 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
            __builtin_amdgcn_readlane(v, 48);
 }
 
+// two 16-bit counters -> both clamped to 255 (one packed min), and the low bytes of four such halves -> one table dword
+typedef unsigned short U16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t clamp255_pair(uint32_t x) {
+    const U16x2 lim = {255, 255};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(U16x2, x), lim));
+}
+__device__ __forceinline__ uint32_t pack_low_bytes(uint32_t x0, uint32_t x1) {      // 0x00bb00aa, 0x00dd00cc -> 0xddccbbaa
+    return __builtin_amdgcn_perm(x1, x0, 0x06040200u);
+}
+
 struct SliceTally {
     int d1 = 0, d2 = 0;
+    // Four table bytes: how many equal 1, how many equal 2 (two bit planes and a population count each); whatever is 3 or
+    // more goes to the LDS bins one byte at a time.  Bytes above 3 are first taken out of the planes.
     __device__ __forceinline__ void add_dword(int *dh, uint32_t x, int sign) {
-        const uint32_t z = swar_zero(x), one = swar_zero(x ^ 0x01010101u), two = swar_zero(x ^ 0x02020202u);
-        d1 += sign * (int)__builtin_popcount(one);
-        d2 += sign * (int)__builtin_popcount(two);
-        uint32_t rest = ~(z | one | two) & 0x80808080u;
+        uint32_t p0 = x & 0x01010101u, p1 = (x >> 1) & 0x01010101u;
+        uint32_t rest = p0 & p1;                                         // bytes equal to 3 (if nothing above)
+        const uint32_t high = x & 0xfcfcfcfcu;
+        if (high) {                                                      // some byte >= 4 (a few per cent of the dwords)
+            const uint32_t big = (((high & 0x7f7f7f7fu) + 0x7f7f7f7fu) | high) & 0x80808080u;   // bit 7 of every such byte
+            const uint32_t keep = ~(big >> 7);
+            p0 &= keep; p1 &= keep;
+            rest = (p0 & p1) | (big >> 7);
+        }
+        const int n1 = (int)__builtin_popcount(p0 & ~p1), n2 = (int)__builtin_popcount(p1 & ~p0);
+        d1 += sign * n1; d2 += sign * n2;
         while (rest) {
-            const int bit = __ffs(rest) - 1;                             // 7, 15, 23 or 31
-            atomicAdd(&dh[(x >> (bit - 7)) & 0xffu], sign);
+            const int bit = __ffs(rest) - 1;                             // 0, 8, 16 or 24
+            atomicAdd(&dh[(x >> bit) & 0xffu], sign);
             rest &= rest - 1u;
         }
     }
@@ -273,10 +295,8 @@ __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ r
                 for (int q = 0; q < 4; q++) tally.add_dword(dh, w[q], -1);
             }
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                uint32_t lo = (w[q >> 1] >> (16 * (q & 1))) & 0xffu, hi = (w[q >> 1] >> (16 * (q & 1) + 8)) & 0xffu;
-                cnt[g * 8 + q] = lo | (hi << 16);
-            }
+            for (int q = 0; q < 8; q++)                                  // bytes b, b + 1 -> the halves of one counter dword
+                cnt[g * 8 + q] = __builtin_amdgcn_perm(0u, w[q >> 1], (q & 1) ? 0x0c030c02u : 0x0c010c00u);
         }
     } else {
         for (uint32_t a = threadIdx.x; a < n_addr / 2; a += T) cnt[a] = slice[2 * a] | ((uint32_t)slice[2 * a + 1] << 16);
@@ -301,16 +321,20 @@ __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ r
     auto count8 = [&](const uint4 &v, uint32_t i) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         if (LEAN && !by_rec) {
-            // a record outside the bucket or the part adds zero.  (Round 1 merged equal neighbours first, for what was left
-            // of tandem runs; the level-1 sort now drops those across lanes, and the merge cost more vector instructions
-            // than the adds it saved.)
+            // Whole buckets only (split_bits == 0: every record of the bucket is below 2^fb_bits, the level-2 sort masked
+            // it).  Four vector instructions and one LDS add per record: the counter's byte offset, and 1 or 0x10000 by
+            // the address's lowest bit.  (Round 1 merged equal neighbours first, for what was left of tandem runs; the
+            // level-1 sort now drops those, and the merge cost more instructions than the adds it saved.)
             const bool interior = i >= start && i + 8u <= end;
+            uint8_t *cb = reinterpret_cast<uint8_t *>(cnt);
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-                const uint32_t full = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-                const bool in = (interior || (i + q >= start && i + q < end)) && (full >> part_bits) == part;
-                const uint32_t a = full & (n_addr - 1u);
-                atomicAdd(&cnt[a >> 1], in ? (1u << (16u * (a & 1u))) : 0u);
+                const uint32_t x = w[q >> 1];
+                const uint32_t off = (q & 1) ? ((x >> 15) & 0x1fffcu) : ((x << 1) & 0x1fffcu);
+                const uint32_t low = (q & 1) ? ((x >> 16) & 1u) : (x & 1u);
+                uint32_t val = low * 0xffffu + 1u;
+                if (!interior) val = (i + q >= start && i + q < end) ? val : 0u;
+                __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(cb + off), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             return;
         }
@@ -378,8 +402,7 @@ __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ r
             __syncthreads();
             if (p1 < end) {                                              // more to come: clamp so nothing can overflow
                 for (uint32_t a = threadIdx.x; a < max(n_addr / 2, 1u); a += T) {
-                    uint32_t x = cnt[a], lo = x & 0xffffu, hi = x >> 16;
-                    cnt[a] = (lo > 255u ? 255u : lo) | ((hi > 255u ? 255u : hi) << 16);
+                    cnt[a] = clamp255_pair(cnt[a]);
                 }
                 __syncthreads();
             }
@@ -388,13 +411,9 @@ __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ r
     // clamp to u8 and write the slice back, 16 addresses per lane
     if (n_addr >= 16) {
         for (uint32_t g = threadIdx.x; g < n_addr / 16; g += T) {
-            uint32_t o[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                uint32_t x = cnt[g * 8 + q], lo = x & 0xffffu, hi = x >> 16;
-                lo = lo > 255u ? 255u : lo; hi = hi > 255u ? 255u : hi;
-                o[q >> 1] |= (lo | (hi << 8)) << (16 * (q & 1));
-            }
+            const uint4 c0 = reinterpret_cast<const uint4 *>(cnt)[g * 2], c1 = reinterpret_cast<const uint4 *>(cnt)[g * 2 + 1];
+            const uint32_t o[4] = {pack_low_bytes(clamp255_pair(c0.x), clamp255_pair(c0.y)), pack_low_bytes(clamp255_pair(c0.z), clamp255_pair(c0.w)),
+                                   pack_low_bytes(clamp255_pair(c1.x), clamp255_pair(c1.y)), pack_low_bytes(clamp255_pair(c1.z), clamp255_pair(c1.w))};
             if (!by_rec) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) tally.add_dword(dh, o[q], 1);
@@ -610,8 +629,8 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
 
 void part_set_attributes() {
     fuse_set_attributes();
-    hipFuncSetAttribute((const void *)k_scatter2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
-    hipFuncSetAttribute((const void *)k_scatter2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
+    hipFuncSetAttribute((const void *)k_scatter2<false, SC_T, SC_PER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
+    hipFuncSetAttribute((const void *)k_scatter2<true, 512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_bucket_count<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute((const void *)k_bucket_count_half<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute((const void *)k_bucket_count_half_lean<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -649,7 +668,7 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     if (laid_out2) {
         static const uint32_t xcd_affine = getenv("PK_XCD") ? (uint32_t)atoi(getenv("PK_XCD")) : 1u;
         static const uint32_t grid2 = getenv("PK_GRID2") ? (uint32_t)atoi(getenv("PK_GRID2")) : 512u;      // 256 CUs x 2; a multiple of 8
-        hipLaunchKernelGGL(k_scatter2<true>, dim3(grid2), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
+        hipLaunchKernelGGL((k_scatter2<true, 512, 32>), dim3(grid2), dim3(512), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
                            bucket_base, bucket_end, (const uint32_t *)nullptr, final_start, pl, out2, cursor2, (const uint32_t *)cap2_end,
                            (uint32_t)pl.capacity2, flags, xcd_affine);
         final_recs = (const uint16_t *)out2; k6_start = final_start; k6_end = cursor2;   // a final bucket ends where its cursor stopped
@@ -657,7 +676,7 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
         hipLaunchKernelGGL(k_count2, dim3(pl.n_wg2_max), dim3(WG), 0, s, (const uint32_t *)out1, wg2_start, bucket_base, bucket_end, pl, hist2,
                            (const uint32_t *)flags);
         hipLaunchKernelGGL(k_rows2_scan, dim3(pl.B1), dim3(512), 0, s, hist2, rowoff2, wg2_start, compact_base, pl, final_start, (const uint32_t *)flags);
-        hipLaunchKernelGGL(k_scatter2<false>, dim3(pl.n_wg2_max), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
+        hipLaunchKernelGGL((k_scatter2<false, SC_T, SC_PER>), dim3(pl.n_wg2_max), dim3(SC_T), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
                            bucket_base, bucket_end, rowoff2, final_start, pl, out2, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, flags, 0u);
         final_recs = (const uint16_t *)out2; k6_start = final_start; k6_end = nullptr;
     }
