@@ -393,4 +393,169 @@ __device__ __forceinline__ L2 piece_l2(const uint8_t *lds, uint32_t nb, uint32_t
     return piece_l2_at(lds + threadIdx.x * LDS_STRIDE, nb, ls_in, km1);
 }
 
+
+// ---------------------------------------------------------------- one classification per piece ----
+// The structure pass looks at every byte once and leaves, for every 64-byte piece, what the squeeze pass needs of it:
+// the 2-bit codes of its valid bases pushed together (text order, base j at bits 2j), one restart bit per base (a
+// character that maps to None lay between it and the base before, indexer.py:36-41,144) and three counts.  The squeeze
+// pass then reads these 32 bytes instead of the 64 bytes of text -- it only adds what depends on the parser state the
+// piece is entered with.  (Until the middle of round 2 both passes classified the text: 35 vector instructions per byte
+// between them, three quarters of it the same SWAR tests twice.)  Pieces that need the byte-wise machine (a header, a
+// blank, a control byte; or entered inside a header line) carry a record too, but it is not used.
+struct PiecePack {
+    unsigned long long c_lo, c_hi;     // codes of bases 0-31, 32-63
+    unsigned long long restart;        // bit j: base j restarts the run -- without what the incoming state adds at base 0
+    uint32_t meta;                     // valid bases | sequence characters (valid or not) << 8 | first byte is a sequence character << 16
+    uint32_t pad_;
+};
+static_assert(sizeof(PiecePack) == 32, "two 16-byte stores per piece");
+__device__ __forceinline__ uint32_t pack_n_valid(const PiecePack &p) { return p.meta & 0xffu; }
+__device__ __forceinline__ uint32_t pack_n_seq(const PiecePack &p) { return (p.meta >> 8) & 0xffu; }
+__device__ __forceinline__ bool pack_first_is_seq(const PiecePack &p) { return (p.meta >> 16) & 1u; }
+
+__device__ __forceinline__ uint32_t revpairs32(uint32_t x) {            // 2-bit field p -> field 15 - p
+    const uint32_t y = __builtin_bitreverse32(x);
+    return ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u);
+}
+__device__ __forceinline__ uint32_t movemask4(uint32_t flags80) {       // 0x80-per-byte flags -> 4 bits, byte 0 lowest
+    return (flags80 * 0x00204081u) >> 28;
+}
+
+// What classify_piece finds in the piece's nb bytes (byte i <-> bit i); bytes past nb count as terminators.
+struct PieceMasks {
+    unsigned long long term, valid, bad;   // line terminator; ACGTacgt; needs the byte-wise machine (blank / control byte that is no terminator, or '>')
+};
+
+// `mine`: the piece's 64 bytes (16-byte aligned).  All lanes of the wave call it together.
+__device__ __forceinline__ void classify_piece(const uint8_t *mine, uint32_t nb, PieceMasks &m, PiecePack &pk) {
+    const uint4 *quads = reinterpret_cast<const uint4 *>(mine);
+    uint32_t vm[2] = {0, 0}, cw[4] = {0, 0, 0, 0};                     // valid bases, codes (byte i -> bits 2i)
+#pragma unroll
+    for (int q = 0; q < PIECE / 16; q++) {
+        const uint4 v = quads[q];
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t w = w4[j];
+            const int d = q * 4 + j;                                     // dword index in the piece: bytes 4d .. 4d+3
+            // the letter bits 2-1 stand for: 00 A, 01 C, 11 G, 10 T (either case)
+            const uint32_t s1 = w >> 1, s2 = w >> 2;
+            const uint32_t is_t = (s2 & ~s1) & 0x01010101u;
+            const uint32_t diff = (w & 0xD9D9D9D9u) ^ 0x41414141u ^ (is_t | (is_t << 4));   // zero byte <=> that letter
+            const uint32_t valid = swar_zero(diff);
+            const uint32_t b = s1 & 0x03030303u;
+            const uint32_t code = b ^ ((b >> 1) & 0x01010101u);          // A 0, C 1, G 2, T 3
+            const uint32_t code8 = (code * 0x01041040u) >> 24;           // byte i -> bits 2i .. 2i+1 of one byte
+            vm[d >> 3] |= movemask4(valid) << (4 * (d & 7));
+            cw[d >> 2] |= code8 << (8 * (d & 3));
+        }
+    }
+    const unsigned long long in_range = nb >= 64u ? ~0ull : ((1ull << nb) - 1ull);
+    const unsigned long long V = ((((unsigned long long)vm[1]) << 32) | vm[0]) & in_range;
+    // everything that is no base -- in plain sequence text one line terminator per piece -- is looked at byte by byte;
+    // a wave that holds a piece with many of them (a run of N, a header) tests all bytes four at a time instead
+    unsigned long long T = ~in_range, bad = 0, todo = ~V & in_range;
+    if (__any(__popcll(todo) > 6)) {
+        uint32_t tm[2] = {0, 0}, bm[2] = {0, 0};
+#pragma unroll
+        for (int q = 0; q < PIECE / 16; q++) {
+            const uint4 v = quads[q];
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int d = q * 4 + j;
+                const uint32_t t = swar_zero(w4[j] ^ 0x0a0a0a0au) | swar_zero(w4[j] ^ 0x0d0d0d0du);
+                const uint32_t bd = (swar_less(w4[j], 0x21212121u) & ~t) | swar_zero(w4[j] ^ 0x3e3e3e3eu);
+                tm[d >> 3] |= movemask4(t) << (4 * (d & 7));
+                bm[d >> 3] |= movemask4(bd) << (4 * (d & 7));
+            }
+        }
+        T |= ((((unsigned long long)tm[1]) << 32) | tm[0]) & in_range;
+        bad = ((((unsigned long long)bm[1]) << 32) | bm[0]) & in_range;
+    } else {
+        while (__any(todo != 0ull)) {
+            if (todo) {
+                const uint32_t p = (uint32_t)__builtin_ctzll(todo);
+                const uint32_t c = mine[p];
+                const unsigned long long bit = 1ull << p;
+                if (is_term(c)) T |= bit;
+                else if (c < 0x21u || c == '>') bad |= bit;
+                todo &= todo - 1ull;
+            }
+        }
+    }
+    m.term = T; m.valid = V; m.bad = bad;
+    const unsigned long long S = ~T;                                      // sequence characters, valid or not (a clean piece has nothing else)
+    const unsigned long long none = S & ~V;                               // characters that map to None
+    // restart flags: carry from every None position through the non-base positions above it into the next base
+    unsigned long long F = ((~V) + none) & V;
+    const uint32_t nv = (uint32_t)__popcll(V);
+    // push the bases together: delete the non-base positions below the highest base, one at a time
+    unsigned long long c_lo = ((unsigned long long)cw[1] << 32) | cw[0], c_hi = ((unsigned long long)cw[3] << 32) | cw[2];
+    // (not in a piece that goes to the byte-wise machine anyway: header text is mostly holes)
+    unsigned long long holes = (V && !bad) ? (~V & ((1ull << (63 - __builtin_clzll(V))) - 1ull)) : 0ull;
+    // A whole RUN of neighbouring holes goes at once (the Ns before the first base after a gap: up to 63 positions,
+    // which one-at-a-time deletion turned into 63 rounds for the whole wave -- 0.3 ms of the structure pass on a genome
+    // with 3 % N).  Plain text has one line terminator per piece, now and then two: two deletions are laid out straight
+    // (a lane without a hole deletes nothing), and only a wave that holds a piece with more runs loops.
+    auto delete_lowest_run = [&]() {
+        const bool any = holes != 0ull;
+        const uint32_t p = any ? (uint32_t)__builtin_ctzll(holes) : 0u;
+        const uint32_t L = any ? (uint32_t)__builtin_ctzll(~(holes >> p)) : 0u;       // p + L <= 63: the highest base lies above
+        const unsigned long long low = any ? ((1ull << p) - 1ull) : ~0ull;
+        F = (F & low) | ((F >> L) & ~low);
+        holes = (holes >> L) & ~low;
+        // the same on the 128 bits of codes: fields below p stay, fields above move down by L
+        const unsigned long long low_lo = !any || p >= 32u ? ~0ull : ((1ull << (2u * p)) - 1ull);
+        const unsigned long long low_hi = !any ? ~0ull : (p <= 32u ? 0ull : ((1ull << (2u * (p - 32u))) - 1ull));
+        const uint32_t sh = 2u * L;                                                   // 0 .. 126
+        unsigned long long s_lo, s_hi;
+        if (sh >= 64u) { s_lo = c_hi >> (sh - 64u); s_hi = 0ull; }
+        else if (sh) { s_lo = (c_lo >> sh) | (c_hi << (64u - sh)); s_hi = c_hi >> sh; }
+        else { s_lo = c_lo; s_hi = c_hi; }
+        c_lo = (c_lo & low_lo) | (s_lo & ~low_lo);
+        c_hi = (c_hi & low_hi) | (s_hi & ~low_hi);
+    };
+    delete_lowest_run();
+    delete_lowest_run();
+    while (__any(holes != 0ull)) delete_lowest_run();
+    // holes above the highest base were left where they are; clear everything past the nv bases
+    const unsigned long long keep = nv >= 64u ? ~0ull : ((1ull << nv) - 1ull);
+    F &= keep;
+    if (nv < 32u) { c_lo &= (1ull << (2u * nv)) - 1ull; c_hi = 0; }
+    else if (nv < 64u) c_hi &= (1ull << (2u * (nv - 32u))) - 1ull;
+    pk.c_lo = c_lo; pk.c_hi = c_hi; pk.restart = F;
+    pk.meta = nv | ((uint32_t)__popcll(S) << 8) | ((uint32_t)(S & 1ull) << 16);
+    pk.pad_ = 0;
+}
+
+// L2 summary of a clean piece from its masks and pack -- what piece_l2_clean reads off the text backwards:
+// the valid bases after the last character that maps to None, up to k-1 of them.
+__device__ __forceinline__ L2 l2_of_clean_piece(const PieceMasks &m, const PiecePack &pk, uint32_t nb, uint32_t ls_in, uint32_t km1) {
+    if (nb == 0) return l2_identity();
+    const unsigned long long none = ~m.term & ~m.valid;
+    const uint32_t nv = pack_n_valid(pk);
+    uint32_t tail = nv;
+    if (none) {
+        const uint32_t hb = 63u - (uint32_t)__builtin_clzll(none);
+        tail = hb == 63u ? 0u : (uint32_t)__popcll(m.valid >> (hb + 1u));
+    }
+    uint32_t flags = F_NONID | F_PRESET;
+    if (ls_in == LS_SEQ && !(m.term & 1ull)) flags |= F_FRONT;
+    if (none || tail >= km1) flags |= F_BRK;
+    const uint32_t len = tail < km1 ? tail : km1;
+    const uint32_t n16 = len < 16u ? len : 16u;                          // 32 bits hold the newest 16
+    uint32_t bits = 0;
+    if (n16) {
+        const uint32_t from = nv - n16;                                  // first of the n16 newest bases
+        unsigned long long x = from >= 32u ? (pk.c_hi >> (2u * (from - 32u)))
+                                           : (from ? ((pk.c_lo >> (2u * from)) | (pk.c_hi << (64u - 2u * from))) : pk.c_lo);
+        uint32_t x32 = (uint32_t)x;
+        if (n16 < 16u) x32 &= (1u << (2u * n16)) - 1u;
+        bits = revpairs32(x32) >> (32u - 2u * n16);                      // newest base lowest
+    }
+    L2 s; s.flags = flags | (len << 8); s.bits = bits; s.rec = 0; s.p_tail = 0;
+    return s;
+}
+
 }  // namespace pk

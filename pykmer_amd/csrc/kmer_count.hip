@@ -69,13 +69,16 @@ __global__ __launch_bounds__(WG) void k_chunk_l1(const uint8_t *__restrict__ fas
     if (lane == 0) chunk_l1[chunk] = nb ? l1_make(last_term >= 0, state) : 0u;
 }
 
-// Pieces of plain sequence text are summarised four bytes at a time (L1) and from their tail (L2).  Pieces with a header,
-// a blank or a control byte -- or that start inside a header line -- need the byte-wise machines, which cost a wave the same
-// for one lane as for 64: those pieces are queued and worked off 64 per wave pass (a read set has a header every kilobase;
-// each wave then held a few such pieces and every wave took both machines).
+// Every piece is classified once (classify_piece, fasta_fsm.h): which bytes are bases, terminators, or something only the
+// byte-wise machine understands; the bases' codes pushed together; their restart bits.  The L1 / L2 summaries of a piece
+// of plain sequence text come from those masks, and the pack is handed to the squeeze pass, which does not read the text
+// of such pieces again.  Pieces with a header, a blank or a control byte -- or that start inside a header line -- need the
+// byte-wise machines, which cost a wave the same for one lane as for 64: those pieces are queued and worked off 64 per
+// wave pass (a read set has a header every kilobase; each wave then held a few such pieces and every wave took both machines).
 __global__ __launch_bounds__(WG) void k_chunk_l2(const uint8_t *__restrict__ fasta, uint64_t n_bytes,
                                                  const L1 *__restrict__ chunk_l1_state, L2 *__restrict__ chunk_l2,
-                                                 LaneState *__restrict__ lane_state, uint32_t *__restrict__ chunk_odd, uint32_t km1) {
+                                                 LaneState *__restrict__ lane_state, PiecePack *__restrict__ packs,
+                                                 uint32_t *__restrict__ chunk_odd, uint32_t km1) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[WG * LDS_STRIDE];
     __shared__ L1 sh1[WG / 64];
     __shared__ L2 sh2[WG / 64];
@@ -89,11 +92,18 @@ __global__ __launch_bounds__(WG) void k_chunk_l2(const uint8_t *__restrict__ fas
     __syncthreads();
     const uint32_t nb = piece_len(base, n_bytes);
     const uint8_t *mine = lds + threadIdx.x * LDS_STRIDE;
-    // ---- L1: line state.  Full pieces by SWAR; what that flags as dirty, and partial pieces, go to the queue
-    bool dirty = false;
-    L1 my1 = 0u;
+    PieceMasks pm;
+    PiecePack pk;
+    classify_piece(mine, nb, pm, pk);
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(packs + (uint64_t)blockIdx.x * WG + threadIdx.x);
+        dst[0] = make_uint4((uint32_t)pk.c_lo, (uint32_t)(pk.c_lo >> 32), (uint32_t)pk.c_hi, (uint32_t)(pk.c_hi >> 32));
+        dst[1] = make_uint4((uint32_t)pk.restart, (uint32_t)(pk.restart >> 32), pk.meta, 0u);
+    }
+    // ---- L1: line state.  Full pieces of plain text from the masks; the rest (and partial pieces) go to the queue
     const bool full = nb == (uint32_t)PIECE;
-    if (__any(full)) my1 = piece_l1_swar(lds, dirty);      // dirty => the value is not used
+    bool dirty = pm.bad != 0ull;
+    L1 my1 = l1_make(pm.term != 0ull, (pm.term >> 63) ? (uint32_t)LS_START : (uint32_t)LS_SEQ);    // not used if queued
     const bool q1 = !full || dirty;
     if (q1) queue[atomicAdd(&n_queued[0], 1u)] = (uint16_t)threadIdx.x;
     __syncthreads();
@@ -111,10 +121,10 @@ __global__ __launch_bounds__(WG) void k_chunk_l2(const uint8_t *__restrict__ fas
     const L1 st1 = wg_excl_scan_l1(my1, chunk_l1_state[blockIdx.x], sh1, &tot1);
     const uint32_t ls_in = l1_kind(st1);
     ls_of[threadIdx.x] = (uint8_t)ls_in;
-    // ---- L2: record / run state.  Clean pieces from their tail; the rest through the queue again
+    // ---- L2: record / run state.  Clean pieces from their masks; the rest through the queue again
     const bool clean = !dirty && ls_in != LS_HEADER;
     L2 my2 = l2_identity();
-    if (clean) my2 = piece_l2_clean(lds, nb, ls_in, km1);
+    if (clean) my2 = l2_of_clean_piece(pm, pk, nb, ls_in, km1);
     else queue[atomicAdd(&n_queued[1], 1u)] = (uint16_t)threadIdx.x;      // the L1 queue was consumed before the scan's barriers
     __syncthreads();
     for (uint32_t q0 = (threadIdx.x >> 6) * 64u; q0 < n_queued[1]; q0 += WG) {
@@ -278,9 +288,9 @@ void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, L1 *
     hipLaunchKernelGGL(k_scan_l1_tiles, dim3(1), dim3(SCAN_T), 0, s, tile_ws, n_tiles, carry);
     hipLaunchKernelGGL(k_scan_l1_apply, dim3(n_tiles), dim3(SCAN_T), 0, s, in, n_chunks, (const L1 *)tile_ws, out);
 }
-void launch_chunk_l2(const uint8_t *fasta, uint64_t n, const L1 *st1, L2 *chunk_l2, LaneState *lane_state, uint32_t *chunk_odd, uint32_t n_chunks,
+void launch_chunk_l2(const uint8_t *fasta, uint64_t n, const L1 *st1, L2 *chunk_l2, LaneState *lane_state, PiecePack *packs, uint32_t *chunk_odd, uint32_t n_chunks,
                      uint32_t k, hipStream_t s) {
-    hipLaunchKernelGGL(k_chunk_l2, dim3(n_chunks), dim3(WG), 0, s, fasta, n, st1, chunk_l2, lane_state, chunk_odd, k - 1);
+    hipLaunchKernelGGL(k_chunk_l2, dim3(n_chunks), dim3(WG), 0, s, fasta, n, st1, chunk_l2, lane_state, packs, chunk_odd, k - 1);
 }
 void launch_scan_l2(const L2 *in, uint32_t n_chunks, Carry *carry, L2 *out, L2 *tile_ws, uint32_t k, hipStream_t s) {
     const uint32_t n_tiles = (n_chunks + SCAN_T - 1) / SCAN_T;

@@ -31,11 +31,6 @@
 
 namespace pk {
 
-__device__ __forceinline__ uint32_t revpairs32(uint32_t x) {            // 2-bit field p -> field 15 - p
-    const uint32_t y = __builtin_bitreverse32(x);
-    return ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u);
-}
-
 // OR of (x << s) for s = 0 .. n-1 (n even, <= 16): which positions have a restart among the n before-or-at them
 __device__ __forceinline__ uint32_t smear_up(uint32_t x, uint32_t n) {
     const uint32_t y1 = x | (x << 1), y2 = y1 | (y1 << 2), y3 = y2 | (y2 << 4);

@@ -51,93 +51,31 @@ __device__ __forceinline__ void lds_or_bits(uint32_t *dst, uint32_t at, unsigned
     }
 }
 
-// ------------------------------------------------------------------ clean pieces, four bytes at a time ----
-// A CLEAN piece holds nothing but sequence characters and line terminators and does not start inside a header
-// line (the structure pass flags everything else): no record opens,
-// nothing is stripped, every byte above 13 is a sequence character.  Then the byte-wise machine is not needed:
-// per dword, SWAR tests give "terminator", "valid base" (either case; anything else maps to None, indexer.py:36-41)
-// and the 2-bit codes of all four bytes; a multiply gathers the per-byte flags into bit masks.  On the 64-bit masks
-//   restart bits   a valid base restarts the run iff a None character lies between it and the valid base
-//                  before it: adding the None mask into the mask of non-base positions ripples a carry up to
-//                  exactly those bases;
-//   window count   positions with no restart among the k-1 before them (shift-or smear), minus those the
-//                  incoming run is too short for;
-// and the few non-base positions (usually one line terminator) are deleted from the code / restart words one at a time.
-__device__ __forceinline__ uint32_t movemask4(uint32_t flags80) {       // 0x80-per-byte flags -> 4 bits, byte 0 lowest
-    return (flags80 * 0x00204081u) >> 28;
-}
-
-// `mine`: this lane's piece is a clean one; lanes with other pieces run along (wave-uniform loops) and leave no trace.
-__device__ __forceinline__ void squeeze_clean(const uint8_t *piece, SeqWalker &wk, PieceBases &pb, bool mine) {
-    const uint4 *quads = reinterpret_cast<const uint4 *>(piece);
-    uint32_t tm[2] = {0, 0}, vm[2] = {0, 0}, cw[4] = {0, 0, 0, 0};     // terminators, valid bases, codes (byte i -> bits 2i)
-#pragma unroll
-    for (int q = 0; q < PIECE / 16; q++) {
-        const uint4 v = quads[q];
-        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t w = w4[j];
-            const int d = q * 4 + j;                                     // dword index in the piece: bytes 4d .. 4d+3
-            // terminator (or fill past the end of the stream): bits 7-5 all clear -- a clean piece has no other byte below 0x20
-            const uint32_t hi3 = w | (w << 1) | (w << 2);
-            const uint32_t term = ~hi3 & 0x80808080u;
-            // the letter bits 2-1 stand for: 00 A, 01 C, 11 G, 10 T (either case)
-            const uint32_t s1 = w >> 1, s2 = w >> 2;
-            const uint32_t is_t = (s2 & ~s1) & 0x01010101u;
-            const uint32_t diff = (w & 0xD9D9D9D9u) ^ 0x41414141u ^ (is_t | (is_t << 4));   // zero byte <=> that letter
-            const uint32_t valid = swar_zero(diff);
-            const uint32_t b = s1 & 0x03030303u;
-            const uint32_t code = b ^ ((b >> 1) & 0x01010101u);          // A 0, C 1, G 2, T 3
-            const uint32_t code8 = (code * 0x01041040u) >> 24;           // byte i -> bits 2i .. 2i+1 of one byte
-            tm[d >> 3] |= movemask4(term) << (4 * (d & 7));
-            vm[d >> 3] |= movemask4(valid) << (4 * (d & 7));
-            cw[d >> 2] |= code8 << (8 * (d & 3));
-        }
-    }
-    const unsigned long long T = ((unsigned long long)tm[1] << 32) | tm[0];
-    unsigned long long V = ((unsigned long long)vm[1] << 32) | vm[0];
-    const unsigned long long S = ~T;                                      // sequence characters, valid or not
-    const unsigned long long none = S & ~V;                               // characters that map to None
-    const uint32_t n_seq = (uint32_t)__popcll(S);
-    if (mine) wk.seq_acc += n_seq;                                        // indexer.py:77: valid or not
+// ------------------------------------------------------------------ clean pieces ----
+// A CLEAN piece holds nothing but sequence characters and line terminators and does not start inside a header line
+// (the structure pass flags everything else): no record opens, nothing is stripped.  The structure pass has already
+// classified its bytes and pushed its bases together (PiecePack, fasta_fsm.h); what is added here is what depends on
+// the state the piece is entered with:
+//   restart bit of base 0   the run was already broken when the piece began;
+//   window count            positions with no restart among the k-1 before them (shift-or smear), minus those the
+//                           incoming run is too short for (indexer.py:144);
+//   tallies                 sequence characters (valid or not, indexer.py:77), pending blanks that turn out interior.
+// `mine`: this lane's piece is a clean one; other lanes run along and leave no trace.
+__device__ __forceinline__ void squeeze_apply(const PiecePack &pk, SeqWalker &wk, PieceBases &pb, bool mine) {
+    const uint32_t nv = pack_n_valid(pk);
+    if (mine) wk.seq_acc += pack_n_seq(pk);                               // indexer.py:77: valid or not
     // blanks pending from the piece before (that piece was not a clean one; this one is): interior if sequence text
     // follows -- each maps to None and the run breaks -- and stripped if the line ends here (indexer.py:56)
     if (mine && wk.pend) {
-        if (S & 1ull) { wk.seq_acc += wk.pend; wk.run = 0u; }
+        if (pack_first_is_seq(pk)) { wk.seq_acc += wk.pend; wk.run = 0u; }
         wk.pend = 0;
     }
     const bool live = mine && wk.rec != 0;                                // text before the first header is dropped
-    // restart flags: carry from every None position through the non-base positions above it into the next base
-    unsigned long long F = ((~V) + none) & V;
-    if (wk.run == 0u) F |= V & (0ull - V);                                // the run was already broken when the piece began
-    const uint32_t nv = (uint32_t)__popcll(V);
-    // windows: compacted positions 0 .. nv-1; compact the restart flags first (delete the non-base positions)
-    unsigned long long c_lo = ((unsigned long long)cw[1] << 32) | cw[0], c_hi = ((unsigned long long)cw[3] << 32) | cw[2];
-    unsigned long long holes = (V && mine) ? (~V & ((1ull << (63 - __builtin_clzll(V))) - 1ull)) : 0ull;   // below the highest base only
-    while (__any(holes != 0ull)) {
-        if (holes) {
-            const uint32_t p = (uint32_t)__builtin_ctzll(holes);
-            const unsigned long long low = (1ull << p) - 1ull;
-            F = (F & low) | ((F >> 1) & ~low);
-            holes = (holes >> 1) & ~low;
-            if (p < 32u) {
-                const unsigned long long low2 = (1ull << (2u * p)) - 1ull;
-                c_lo = (c_lo & low2) | (((c_lo >> 2) | (c_hi << 62)) & ~low2);
-                c_hi >>= 2;
-            } else {
-                const unsigned long long low2 = (1ull << (2u * (p - 32u))) - 1ull;
-                c_hi = (c_hi & low2) | ((c_hi >> 2) & ~low2);
-            }
-        }
-    }
-    // holes above the highest base were left where they are; clear everything past the nv bases
+    unsigned long long F = pk.restart;
+    if (wk.run == 0u && nv) F |= 1ull;                                    // the run was already broken when the piece began
     const unsigned long long keep = nv >= 64u ? ~0ull : ((1ull << nv) - 1ull);
-    F &= keep;
-    if (nv < 32u) { c_lo &= (1ull << (2u * nv)) - 1ull; c_hi = 0; }
-    else if (nv < 64u) c_hi &= (1ull << (2u * (nv - 32u))) - 1ull;
-    // valid windows ending in this piece (indexer.py:144): no restart among the k-1 positions behind the window's
-    // first base, and -- where no restart precedes -- enough bases carried in
+    // valid windows ending in this piece: no restart among the k-1 positions behind the window's first base, and --
+    // where no restart precedes -- enough bases carried in
     const uint32_t km1 = wk.k - 1u;
     unsigned long long X = 0;
     {
@@ -155,7 +93,7 @@ __device__ __forceinline__ void squeeze_clean(const uint8_t *piece, SeqWalker &w
     const unsigned long long below_first = F ? ((F & (0ull - F)) - 1ull) : ~0ull;
     const unsigned long long has = ~X & ~(lead & below_first) & keep;
     wk.kmer_acc += live ? (uint64_t)__popcll(has) : 0ull;
-    pb.code_lo = live ? c_lo : 0ull; pb.code_hi = live ? c_hi : 0ull;
+    pb.code_lo = live ? pk.c_lo : 0ull; pb.code_hi = live ? pk.c_hi : 0ull;
     pb.restart = live ? F : 0ull;
     pb.n = live ? nv : 0u;
 }
@@ -194,12 +132,13 @@ __device__ __forceinline__ void stage_image(const uint8_t *__restrict__ fasta, u
 }
 
 __global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
-                                                const LaneState *__restrict__ lane_state, const L2 *__restrict__ chunk_l2_state,
+                                                const LaneState *__restrict__ lane_state, const PiecePack *__restrict__ packs,
+                                                const L2 *__restrict__ chunk_l2_state,
                                                 const uint32_t *__restrict__ chunk_odd, uint32_t k, uint32_t n_chunks, uint32_t chunks_per_wg,
                                                 uint32_t *__restrict__ codes,
                                                 uint32_t *__restrict__ restarts, uint32_t *__restrict__ n_bases,
                                                 DevRec *__restrict__ recs, uint64_t recs_cap, Carry *carry) {
-    __shared__ __attribute__((aligned(16))) uint8_t image[2][CHUNK];
+    __shared__ __attribute__((aligned(16))) uint8_t image[2][CHUNK];   // text of chunks that hold pieces for the byte-wise machine
     __shared__ __attribute__((aligned(16))) uint32_t slot_codes[SLOT_CODE_WORDS + 8];   // + slack: lds_or_bits touches up to 5 words
     __shared__ __attribute__((aligned(16))) uint32_t slot_rst[SLOT_RST_WORDS + 8];
     __shared__ uint32_t scan_sh[WG / 64];
@@ -214,12 +153,34 @@ __global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fast
     SeqWalker wk;
     wk.setup(k, recs, recs_cap, &racc);
     const uint32_t c_lo = blockIdx.x * chunks_per_wg, c_hi = min(c_lo + chunks_per_wg, n_chunks);
-    if (c_lo < c_hi) stage_image(fasta, (uint64_t)c_lo * CHUNK, n_bytes, image[0]);
+    // Per chunk a lane needs its state (8 bytes) and its pack (32 bytes).  Both are requested one chunk AHEAD and taken
+    // delivery of right before the current chunk's slot is stored (settle, as in the sort kernels: loads and stores
+    // share one in-order counter, and a load waited for after the stores would also wait for the stores).  The text
+    // itself is only fetched -- by LDS-DMA, also one chunk ahead -- for chunks with pieces the byte-wise machine must see.
+    struct Fetched { uint32_t ls_flags, ls_rec_tail; uint4 p0, p1; };
+    auto fetch = [&](uint32_t c, Fetched &f) {
+        const LaneState l = lane_state[(uint64_t)c * WG + threadIdx.x];
+        f.ls_flags = l.flags; f.ls_rec_tail = l.rec_tail;
+        const uint4 *src = reinterpret_cast<const uint4 *>(packs + (uint64_t)c * WG + threadIdx.x);
+        f.p0 = src[0]; f.p1 = src[1];
+    };
+    Fetched nxt;
+    auto settle = [&]() {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): also the next chunk's image, if one was requested
+        asm volatile("" : "+v"(nxt.ls_flags), "+v"(nxt.ls_rec_tail), "+v"(nxt.p0.x), "+v"(nxt.p0.y), "+v"(nxt.p0.z), "+v"(nxt.p0.w),
+                          "+v"(nxt.p1.x), "+v"(nxt.p1.y), "+v"(nxt.p1.z), "+v"(nxt.p1.w));
+    };
+    if (c_lo < c_hi) {
+        if (chunk_odd[c_lo]) stage_image(fasta, (uint64_t)c_lo * CHUNK, n_bytes, image[0]);
+        fetch(c_lo, nxt);
+    }
+    settle();
+    __syncthreads();
     for (uint32_t c = c_lo; c < c_hi; c++) {
         const uint64_t base = (uint64_t)c * CHUNK;
         uint8_t *buf = image[(c - c_lo) & 1u];
-        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's share of the image has landed ...
-        __syncthreads();                                   // ... and so has everyone else's; the other image is free (its readers passed the last barrier)
+        const bool all_clean = chunk_odd[c] == 0u;         // uniform over the workgroup; the usual chunk
+        if (!all_clean) __syncthreads();                   // every wave's share of the image has landed (each waited for its own in settle)
         // the record tallies of a chunk count up from the record it starts in; when that moves on, what was gathered
         // is written out (a genome keeps one window for thousands of chunks, a read set moves it with every chunk)
         const uint32_t first_rec = chunk_l2_state[c].rec;
@@ -229,23 +190,32 @@ __global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fast
             if (threadIdx.x == 0) racc.rec0 = first_rec;
             __syncthreads();
         }
-        if (c + 1 < c_hi) stage_image(fasta, base + CHUNK, n_bytes, image[(c - c_lo + 1) & 1u]);
+        const Fetched me = nxt;
+        if (c + 1 < c_hi) {
+            // the other image is free: its readers passed the barriers of the chunk before this one
+            if (chunk_odd[c + 1]) stage_image(fasta, base + CHUNK, n_bytes, image[(c - c_lo + 1) & 1u]);
+            fetch(c + 1, nxt);
+        }
         // exact parser state at this lane's first byte: chunk state . lane prefix (both from the structure pass)
         const L2 chunk_st = chunk_l2_state[c];
-        const LaneState lst = lane_state[(uint64_t)c * WG + threadIdx.x];
+        LaneState lst; lst.flags = me.ls_flags; lst.rec_tail = me.ls_rec_tail;
         const L2 st2 = l2_compose(chunk_st, lane_state_l2(lst), km1);
         const uint32_t ls_in = lane_state_ls(lst);
         wk.begin(ls_in, st2, stream_off + base + (uint64_t)threadIdx.x * PIECE);
         uint8_t *piece = buf + threadIdx.x * PIECE;
         PieceBases pb;
         pb.clear();
-        // Plain sequence text goes four bytes at a time.  Pieces with a header, a blank or a control byte need the
-        // byte-wise machine, which costs the same for one lane as for 64: they are queued, and the queue is worked
-        // off 64 pieces per wave pass -- with a header every kilobase (read sets) that is one pass per workgroup
-        // instead of one per wave.  A queued piece's result is left in the piece's own 64 bytes of the image.
+        // Plain sequence text: the structure pass's pack plus this lane's state.  Pieces with a header, a blank or a
+        // control byte need the byte-wise machine, which costs the same for one lane as for 64: they are queued, and the
+        // queue is worked off 64 pieces per wave pass -- with a header every kilobase (read sets) that is one pass per
+        // workgroup instead of one per wave.  A queued piece's result is left in the piece's own 64 bytes of the image.
         const bool clean = !lane_state_dirty(lst) && ls_in != LS_HEADER;             // the structure pass's definition: chunk_odd counts the rest
-        const bool all_clean = chunk_odd[c] == 0u;                                  // uniform over the workgroup; the usual chunk
-        if (all_clean || __any(clean)) squeeze_clean(piece, wk, pb, clean);
+        {
+            PiecePack pk;
+            pk.c_lo = ((unsigned long long)me.p0.y << 32) | me.p0.x; pk.c_hi = ((unsigned long long)me.p0.w << 32) | me.p0.z;
+            pk.restart = ((unsigned long long)me.p1.y << 32) | me.p1.x; pk.meta = me.p1.z; pk.pad_ = 0;
+            if (all_clean || __any(clean)) squeeze_apply(pk, wk, pb, clean);
+        }
         if (!all_clean) {
             if (!clean) queue[atomicAdd(&n_queued, 1u)] = (uint16_t)threadIdx.x;
             __syncthreads();
@@ -289,6 +259,7 @@ __global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fast
         lds_or_bits(slot_codes, 2u * at, pb.code_lo, pb.code_hi, 2u * pb.n);
         lds_or_bits(slot_rst, at, pb.restart, 0ull, pb.n);
         __syncthreads();
+        settle();
         // slot -> HBM, 16 bytes per lane, only the words that hold bases; the LDS copy is cleared for the next chunk
         const uint32_t code_q = (total + 63u) / 64u, rst_q = (total + 127u) / 128u;      // uint4 groups in use
         uint4 *gc = reinterpret_cast<uint4 *>(codes + (uint64_t)c * SLOT_CODE_WORDS);
@@ -307,10 +278,10 @@ __global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fast
     recacc_finish(racc, recs, recs_cap, carry);
 }
 
-void launch_squeeze(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2,
+void launch_squeeze(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const PiecePack *packs, const L2 *st2,
                     const uint32_t *chunk_odd, uint32_t k, uint32_t n_chunks, uint32_t n_wg, uint32_t chunks_per_wg, uint32_t *codes, uint32_t *restarts, uint32_t *n_bases,
                     DevRec *recs, uint64_t recs_cap, Carry *carry, hipStream_t s) {
-    hipLaunchKernelGGL(k_squeeze, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, st2, chunk_odd, k, n_chunks, chunks_per_wg, codes,
+    hipLaunchKernelGGL(k_squeeze, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, packs, st2, chunk_odd, k, n_chunks, chunks_per_wg, codes,
                        restarts, n_bases, recs, recs_cap, carry);
 }
 

@@ -200,6 +200,7 @@ struct pk_indexer {
     L1 *c_l1 = nullptr, *c_l1s = nullptr;
     L2 *c_l2 = nullptr, *c_l2s = nullptr;
     LaneState *lane_state = nullptr;   // per 64-byte piece: start state relative to its chunk
+    PiecePack *packs = nullptr;        // per 64-byte piece: its bases, classified and pushed together (structure pass -> squeeze pass)
     uint32_t *chunk_odd = nullptr;     // per chunk: pieces that are not plain sequence text
     L1 *t_l1 = nullptr;                // scan scratch: one summary per 1024 chunks
     L2 *t_l2 = nullptr;
@@ -246,7 +247,7 @@ extern "C" void pk_indexer_destroy(pk_indexer *ix) {
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
     hipFree(ix->table8); hipFree(ix->carry); hipFree(ix->hist); hipFree(ix->recs);
-    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state); hipFree(ix->chunk_odd); hipFree(ix->t_l1); hipFree(ix->t_l2); hipFree(ix->staging[0]); hipFree(ix->staging[1]); hipFree(ix->ws);
+    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state); hipFree(ix->packs); hipFree(ix->chunk_odd); hipFree(ix->t_l1); hipFree(ix->t_l2); hipFree(ix->staging[0]); hipFree(ix->staging[1]); hipFree(ix->ws);
     for (auto &e : ix->ev) if (e) hipEventDestroy(e);
     if (ix->stream) hipStreamDestroy(ix->stream);
     delete ix;
@@ -293,14 +294,15 @@ extern "C" int pk_indexer_reset(pk_indexer *ix) {
 
 static int ensure_chunks(pk_indexer *ix, uint32_t n_chunks) {
     if (n_chunks <= ix->chunk_cap) return PK_OK;
-    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state); hipFree(ix->chunk_odd); hipFree(ix->t_l1); hipFree(ix->t_l2);
-    ix->c_l1 = ix->c_l1s = nullptr; ix->c_l2 = ix->c_l2s = nullptr; ix->lane_state = nullptr; ix->chunk_odd = nullptr; ix->t_l1 = nullptr; ix->t_l2 = nullptr;
+    hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state); hipFree(ix->packs); hipFree(ix->chunk_odd); hipFree(ix->t_l1); hipFree(ix->t_l2);
+    ix->c_l1 = ix->c_l1s = nullptr; ix->c_l2 = ix->c_l2s = nullptr; ix->lane_state = nullptr; ix->packs = nullptr; ix->chunk_odd = nullptr; ix->t_l1 = nullptr; ix->t_l2 = nullptr;
     ix->chunk_cap = 0;
     HIPCHK(hipMalloc(&ix->c_l1, n_chunks * sizeof(L1)));
     HIPCHK(hipMalloc(&ix->c_l1s, n_chunks * sizeof(L1)));
     HIPCHK(hipMalloc(&ix->c_l2, n_chunks * sizeof(L2)));
     HIPCHK(hipMalloc(&ix->c_l2s, n_chunks * sizeof(L2)));
     HIPCHK(hipMalloc(&ix->lane_state, (size_t)n_chunks * WG * sizeof(LaneState)));
+    HIPCHK(hipMalloc(&ix->packs, (size_t)n_chunks * WG * sizeof(PiecePack)));
     HIPCHK(hipMalloc(&ix->chunk_odd, (size_t)n_chunks * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&ix->t_l1, ((size_t)n_chunks / 1024 + 1) * sizeof(L1)));
     HIPCHK(hipMalloc(&ix->t_l2, ((size_t)n_chunks / 1024 + 1) * sizeof(L2)));
@@ -333,7 +335,7 @@ static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
     HIPCHK(hipEventRecord(ix->ev[0], ix->stream));
     launch_chunk_l1(f, n_bytes, ix->c_l1, n_chunks, ix->stream);
     launch_scan_l1(ix->c_l1, n_chunks, ix->carry, ix->c_l1s, ix->t_l1, ix->stream);
-    launch_chunk_l2(f, n_bytes, ix->c_l1s, ix->c_l2, ix->lane_state, ix->chunk_odd, n_chunks, (uint32_t)ix->k, ix->stream);
+    launch_chunk_l2(f, n_bytes, ix->c_l1s, ix->c_l2, ix->lane_state, ix->packs, ix->chunk_odd, n_chunks, (uint32_t)ix->k, ix->stream);
     launch_scan_l2(ix->c_l2, n_chunks, ix->carry, ix->c_l2s, ix->t_l2, (uint32_t)ix->k, ix->stream);
     HIPCHK(hipEventRecord(ix->ev[1], ix->stream));
     uint64_t n_recs = 0;
@@ -351,7 +353,7 @@ static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
         ix->ws_cap = need;
     }
     HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
-    launch_squeeze(f, n_bytes, ix->bytes_fed, ix->lane_state, ix->c_l2s, ix->chunk_odd, (uint32_t)ix->k, n_chunks, pl.n_wg0, pl.G, (uint32_t *)(ix->ws + lay.codes),
+    launch_squeeze(f, n_bytes, ix->bytes_fed, ix->lane_state, ix->packs, ix->c_l2s, ix->chunk_odd, (uint32_t)ix->k, n_chunks, pl.n_wg0, pl.G, (uint32_t *)(ix->ws + lay.codes),
                    (uint32_t *)(ix->ws + lay.restarts), (uint32_t *)(ix->ws + lay.n_bases), ix->recs, ix->recs_cap, ix->carry, ix->stream);
     HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
     float a = 0, b = 0, c = 0, d = 0, e = 0;

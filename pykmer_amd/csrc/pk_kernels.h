@@ -27,7 +27,7 @@ struct Carry {
 
 void launch_chunk_l1(const uint8_t *fasta, uint64_t n, L1 *chunk_l1, uint32_t n_chunks, hipStream_t s);
 void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, L1 *tile_ws, hipStream_t s);
-void launch_chunk_l2(const uint8_t *fasta, uint64_t n, const L1 *st1, L2 *chunk_l2, LaneState *lane_state, uint32_t *chunk_odd, uint32_t n_chunks,
+void launch_chunk_l2(const uint8_t *fasta, uint64_t n, const L1 *st1, L2 *chunk_l2, LaneState *lane_state, PiecePack *packs, uint32_t *chunk_odd, uint32_t n_chunks,
                      uint32_t k, hipStream_t s);
 void launch_scan_l2(const L2 *in, uint32_t n_chunks, Carry *carry, L2 *out, L2 *tile_ws, uint32_t k, hipStream_t s);
 void launch_hist8(const uint8_t *table8, uint64_t n, unsigned long long *hist, hipStream_t s);
@@ -35,7 +35,7 @@ void launch_hist8(const uint8_t *table8, uint64_t n, unsigned long long *hist, h
 // kmer_pack.hip -- the packed stream: one slot per 16 KiB text chunk
 constexpr uint32_t SLOT_CODE_WORDS = 1024;   // 16384 bases x 2 bits
 constexpr uint32_t SLOT_RST_WORDS = 512;     // 16384 restart bits
-void launch_squeeze(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const L2 *st2,
+void launch_squeeze(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const PiecePack *packs, const L2 *st2,
                     const uint32_t *chunk_odd, uint32_t k, uint32_t n_chunks, uint32_t n_wg, uint32_t chunks_per_wg, uint32_t *codes, uint32_t *restarts, uint32_t *n_bases,
                     DevRec *recs, uint64_t recs_cap, Carry *carry, hipStream_t s);
 
