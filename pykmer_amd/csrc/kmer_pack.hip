@@ -131,7 +131,7 @@ __device__ __forceinline__ void stage_image(const uint8_t *__restrict__ fasta, u
     else stage_image_tail(fasta, chunk_base, n_bytes, buf);
 }
 
-__global__ __launch_bounds__(WG) void k_squeeze(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
+__global__ __launch_bounds__(WG, 4) void k_squeeze(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
                                                 const LaneState *__restrict__ lane_state, const PiecePack *__restrict__ packs,
                                                 const L2 *__restrict__ chunk_l2_state,
                                                 const uint32_t *__restrict__ chunk_odd, uint32_t k, uint32_t n_chunks, uint32_t chunks_per_wg,

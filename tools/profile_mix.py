@@ -24,5 +24,7 @@ for name, kw in cases.items():
             ix.reset(); torch.cuda.synchronize(); t0 = time.perf_counter()
             ix.feed_device(d.data_ptr(), int(fa.size)); fin = ix.finish(); best = min(best, time.perf_counter() - t0)
         t = ix.timings()
-    print(f"{name:22s} {bp/1e6:6.0f} Mbp  {best*1e3:7.2f} ms  {bp/best/1e9:6.1f} Gbp/s  kmers {fin['num_kmers']:>11d}  records {fin['n_records']}", flush=True)
+    print(f"{name:22s} {bp/1e6:6.0f} Mbp  {best*1e3:7.2f} ms  {bp/best/1e9:6.1f} Gbp/s  kmers {fin['num_kmers']:>11d}  records {fin['n_records']}"
+          f"   [all feeds, ms: structure {t['scan_s']*1e3:.2f} squeeze {t['squeeze_s']*1e3:.2f} sort {t['walk_sort_s']*1e3:.2f} "
+          f"layout+level2 {(t['partition_s'] - t['walk_sort_s'])*1e3:.2f} count {t['bucket_s']*1e3:.2f} relayouts {t['relayouts']}]", flush=True)
     del d
