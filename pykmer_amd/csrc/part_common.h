@@ -139,13 +139,20 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     auto digit_of = [&](const RIN &x) -> uint32_t {
         return sizeof(RIN) == 4 ? __builtin_amdgcn_ubfe((uint32_t)x, shift, dbits) : (uint32_t)((uint64_t)x >> shift) & (B - 1u);
     };
-    uint32_t dg[PER <= 16 ? PER : 1];                      // PER <= 16: the digit, or this lane's scratch digit for an empty slot
+    // PER <= 16: the digit, or this lane's scratch digit for an empty slot.  64-bit records do not keep it (the k = 17
+    // kernel is out of registers as it is: 28 were spilled to scratch memory) and cut it from the record again when parking.
+    constexpr bool KEEP_DG = PER <= 16 && sizeof(RIN) == 4;
+    uint32_t dg[KEEP_DG ? PER : 1];
+    auto slot_digit = [&](int j) -> uint32_t { return (FULL || ((okm >> j) & 1u)) ? digit_of(r[j]) : (uint32_t)NB + lane; };
     if (PER <= 16) {
         // branch-free: an LDS operation behind a branch is waited for on the spot, sixteen back to back cost one round trip
+        if (KEEP_DG) {
 #pragma unroll
-        for (int j = 0; j < PER; j++) dg[j] = (FULL || ((okm >> j) & 1u)) ? digit_of(r[j]) : (uint32_t)NB + lane;
+            for (int j = 0; j < PER; j++) dg[KEEP_DG ? j : 0] = slot_digit(j);
+        }
 #pragma unroll
-        for (int j = 0; j < PER; j++) __hip_atomic_fetch_add(&L.hist[dg[j]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int j = 0; j < PER; j++)
+            __hip_atomic_fetch_add(&L.hist[KEEP_DG ? dg[KEEP_DG ? j : 0] : slot_digit(j)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (!FULL && threadIdx.x < 64u) L.off[NB + threadIdx.x] = (uint32_t)TILE + threadIdx.x;   // where empty slots park (adds of zero)
     } else {
         // 32 records per thread: every record under its own test (32 digits in registers spill)
@@ -186,8 +193,9 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     if (PER <= 16) {
 #pragma unroll
         for (int j = 0; j < PER; j++) {
-            const uint32_t p = atomicAdd(&L.off[dg[j]], (FULL || ((okm >> j) & 1u)) ? 1u : 0u);
-            if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)dg[j]; }
+            const uint32_t d = KEEP_DG ? dg[KEEP_DG ? j : 0] : slot_digit(j);
+            const uint32_t p = atomicAdd(&L.off[d], (FULL || ((okm >> j) & 1u)) ? 1u : 0u);
+            if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)d; }
             else L.rec[p] = (uint32_t)r[j];
         }
     } else {
