@@ -29,6 +29,8 @@ def short(name: str) -> str:
         return base + "<" + m.group(2)[1:-1].split(",")[0] + ">"
     if base == "k_walk_sort" and re.search(r"k_walk_sort<[^,]+, true", name):
         return "k_walk_sort_count"                                   # the sampling launch (tallies only)
+    if base.startswith("k_bucket_count"):
+        return "k_bucket_count"                                      # whole / half / half_lean: one of them per feed
     return base
 
 
@@ -51,9 +53,9 @@ def main() -> None:
         "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, `bench.py --steps 2 --warmup 0 --no-cpu`), "
                  "largest dispatch per kernel (= the 800 Mbp k=15 step); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                  "MI355X_MICROARCH.md HBM section (FETCH_SIZE reads half of a wide coalesced stream on gfx950). "
-                 "Calibration: k_gram_blk (N=32) vs 34.36 GB algorithmic; k_chunk_l2 vs 0.813 GB FASTA + 0.203 GB lane states. "
+                 "Calibration: k_gram_blk (N=32) vs 34.36 GB algorithmic; k_chunk_l2 vs 0.813 GB FASTA + 0.102 GB lane states + 0.407 GB piece packs. "
                  "The factor 2 is calibrated for 16-byte-per-lane streams only; k_walk_sort reads 4 bytes per lane (0.3 GB of packed "
-                 "bases) and k_squeeze reads by LDS-DMA, so their read side is approximate -- their traffic is mostly writes. "
+                 "bases) and k_squeeze reads 8 + 32 bytes per lane (states and piece packs), so their read side is approximate -- their traffic is mostly writes. "
                  "Derived by tools/hbm_traffic.py.",
         "_source": [fetch_csv, write_csv],
     }
