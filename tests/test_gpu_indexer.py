@@ -183,6 +183,26 @@ def test_dense_feeds_use_half_size_buckets(gpu, k, n_bp):
         assert np.array_equal(ix.table_to_host(), oracle.count_fasta(dense, k)["table"][2 * quarter: 3 * quarter])
 
 
+@pytest.mark.parametrize("k", [5, 15])
+def test_many_runs_of_invalid_characters_per_piece(gpu, k):
+    """The structure pass pushes a piece's valid bases together by deleting RUNS of other characters (classify_piece):
+    pieces with one run, with a dozen, with more non-bases than the byte-by-byte path takes (> 6: four at a time),
+    at every density, wrapped at odd widths and unwrapped, lower case mixed in."""
+    rng = np.random.default_rng(77)
+    parts = []
+    for i, p_bad in enumerate((0.01, 0.05, 0.2, 0.5, 0.9)):
+        n = 20_000
+        seq = rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), size=n)
+        bad = rng.random(n) < p_bad
+        seq[bad] = rng.choice(np.frombuffer(b"NnRYKMSWBDHV-*.", dtype=np.uint8), size=int(bad.sum()))
+        for a in range(0, n, 997):                                              # a few longer gaps
+            seq[a: a + int(rng.integers(1, 90))] = ord("N")
+        width = (61, 7, 64, 0, 130)[i]
+        body = seq.tobytes() if width == 0 else b"\n".join(seq[j: j + width].tobytes() for j in range(0, n, width))
+        parts.append(b">r%d\n" % i + body + b"\n")
+    _check_against_oracle(gpu, np.frombuffer(b"".join(parts), dtype=np.uint8), k)
+
+
 def test_control_bytes_inside_sequence_lines(gpu):
     """Bytes below 0x21 other than \\n / \\r (NUL, \\x01, tab, VT, FS..US, space) and DEL inside sequence
     text: blanks are stripped at line ends and map to None inside, the rest are plain non-bases.  Such
