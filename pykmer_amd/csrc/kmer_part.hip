@@ -284,7 +284,8 @@ __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ r
     SliceTally tally;
     for (uint32_t i = threadIdx.x; i < 256; i += T) dh[i] = 0;
     if (fresh) {
-        for (uint32_t a = threadIdx.x; a < max(n_addr / 2, 1u); a += T) cnt[a] = 0u;
+        if (n_addr >= 8) for (uint32_t g = threadIdx.x; g < n_addr / 8; g += T) reinterpret_cast<uint4 *>(cnt)[g] = make_uint4(0, 0, 0, 0);
+        else for (uint32_t a = threadIdx.x; a < max(n_addr / 2, 1u); a += T) cnt[a] = 0u;
     } else if (n_addr >= 16) {                                           // fold in what the slice already holds (earlier feeds)
         if (!by_rec) __syncthreads();                                    // dh zeroed before anyone subtracts from it
         for (uint32_t g = threadIdx.x; g < n_addr / 16; g += T) {
@@ -361,11 +362,12 @@ __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ r
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t old[8];
         bool in[8];
+        const bool interior = i >= start && i + 8u <= end;             // all eight records belong to the bucket (nearly every lane)
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const uint32_t idx = i + q;
             const uint32_t full = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-            in[q] = idx >= start && idx < end && (full >> part_bits) == part;
+            in[q] = (interior || (idx >= start && idx < end)) && (full >> part_bits) == part;
             const uint32_t a = full & (n_addr - 1u), sh = 16u * (a & 1u);
             old[q] = (atomicAdd(&cnt[a >> 1], in[q] ? (1u << sh) : 0u) >> sh) & 0xffffu;
         }
