@@ -252,13 +252,6 @@ __device__ __forceinline__ uint32_t piece_len(uint64_t chunk_base, uint64_t n_by
 // count is uniform (callers may use wave-wide ballots inside f); `active` is false past the lane's
 // last byte.  16 bytes are fetched per ds_read_b128 and shifted through four registers.
 template <class Fn>
-__device__ __forceinline__ void for_each_byte_of(const uint8_t *mine, uint32_t nb, Fn &&f);
-template <class Fn>
-__device__ __forceinline__ void for_each_byte(const uint8_t *lds, uint32_t nb, Fn &&f) {
-    for_each_byte_of(lds + threadIdx.x * LDS_STRIDE, nb, f);
-}
-// the same over a piece that starts at `mine` (16-byte aligned, 64 contiguous bytes)
-template <class Fn>
 __device__ __forceinline__ void for_each_byte_of(const uint8_t *mine, uint32_t nb, Fn &&f) {
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
 #pragma unroll 1
@@ -292,72 +285,10 @@ __device__ __forceinline__ L1 piece_l1_at(const uint8_t *mine, uint32_t nb, bool
     dirty = d;
     return nb ? l1_make(ht, st) : 0u;
 }
-__device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb, bool &dirty) {
-    return piece_l1_at(lds + threadIdx.x * LDS_STRIDE, nb, dirty);
-}
-__device__ __forceinline__ L1 piece_l1(const uint8_t *lds, uint32_t nb) {
-    bool dirty;
-    return piece_l1(lds, nb, dirty);
-}
-
 // SWAR helpers: 0x80 in every byte of v that is zero / below n (n <= 128); exact, no cross-byte borrows
 __device__ __forceinline__ uint32_t swar_zero(uint32_t v) { return ~(((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v | 0x7f7f7f7fu); }
 __device__ __forceinline__ uint32_t swar_less(uint32_t v, uint32_t n_rep) {
     return ~((((v & 0x7f7f7f7fu) | 0x80808080u) - n_rep) | v) & 0x80808080u;
-}
-
-// The same summary for a FULL 64-byte piece, four bytes per step: a piece without blanks (other than
-// terminators) and without '>' ends in LS_START if its last byte is a terminator and in LS_SEQ
-// otherwise.  Sets dirty (and returns 0) when the byte-wise machine is needed instead.
-__device__ __forceinline__ L1 piece_l1_swar(const uint8_t *lds, bool &dirty) {
-    const uint4 *mine = reinterpret_cast<const uint4 *>(lds + threadIdx.x * LDS_STRIDE);
-    uint32_t any_term = 0, bad = 0, last = 0;
-#pragma unroll
-    for (int q = 0; q < PIECE / 16; q++) {
-        const uint4 v = mine[q];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t t = swar_zero(w[j] ^ 0x0a0a0a0au) | swar_zero(w[j] ^ 0x0d0d0d0du);
-            any_term |= t;
-            bad |= (swar_less(w[j], 0x21212121u) & ~t) | swar_zero(w[j] ^ 0x3e3e3e3eu);   // blank that is no terminator, or '>'
-            last = t;
-        }
-    }
-    dirty = bad != 0;
-    return l1_make(any_term != 0, (last >> 31) ? (uint32_t)LS_START : (uint32_t)LS_SEQ);
-}
-
-// Wave-uniform front end used by the kernels: SWAR when every lane of the wave holds a full clean
-// piece, the byte-wise machine otherwise.
-__device__ __forceinline__ L1 piece_l1_auto(const uint8_t *lds, uint32_t nb, bool &dirty) {
-    if (__all(nb == (uint32_t)PIECE)) {
-        bool d;
-        L1 r = piece_l1_swar(lds, d);
-        if (__all(!d)) { dirty = false; return r; }
-    }
-    return piece_l1(lds, nb, dirty);
-}
-
-// L2 summary of a CLEAN piece (only sequence characters and terminators, not starting in a header
-// line): no record opens, no whitespace stays pending, so only the trailing <= k-1 valid bases
-// matter -- read backwards from the end instead of walking all 64 bytes.
-__device__ __forceinline__ L2 piece_l2_clean(const uint8_t *lds, uint32_t nb, uint32_t ls_in, uint32_t km1) {
-    if (nb == 0) return l2_identity();
-    const uint8_t *mine = lds + threadIdx.x * LDS_STRIDE;
-    uint32_t flags = F_NONID | F_PRESET, len = 0, bits = 0;
-    if (ls_in == LS_SEQ && !is_term(mine[0])) flags |= F_FRONT;
-    bool open = true;                                        // still collecting
-    for (int i = (int)nb - 1; i >= 0 && open; i--) {
-        const uint32_t c = mine[i];
-        if (is_term(c)) continue;
-        const uint32_t code = base_code(c);
-        if (code > 3u || len >= km1) { flags |= F_BRK; open = false; }
-        else { if (len < 16u) bits |= code << (2u * len); len++; }
-    }
-    if (len >= km1) flags |= F_BRK;
-    L2 s; s.flags = flags | (len << 8); s.bits = bits; s.rec = 0; s.p_tail = 0;
-    return s;
 }
 
 // L2 summary of the lane's piece, given its exact incoming line state.
@@ -387,10 +318,6 @@ __device__ __forceinline__ L2 piece_l2_at(const uint8_t *mine, uint32_t nb, uint
     if (len >= km1) flags |= F_BRK;
     L2 s; s.flags = flags | (len << 8); s.bits = bits; s.rec = rec; s.p_tail = pt;
     return s;
-}
-
-__device__ __forceinline__ L2 piece_l2(const uint8_t *lds, uint32_t nb, uint32_t ls_in, uint32_t km1) {
-    return piece_l2_at(lds + threadIdx.x * LDS_STRIDE, nb, ls_in, km1);
 }
 
 
@@ -529,7 +456,7 @@ __device__ __forceinline__ void classify_piece(const uint8_t *mine, uint32_t nb,
     pk.pad_ = 0;
 }
 
-// L2 summary of a clean piece from its masks and pack -- what piece_l2_clean reads off the text backwards:
+// L2 summary of a clean piece from its masks and pack (round 1 read the piece's tail backwards, byte by byte):
 // the valid bases after the last character that maps to None, up to k-1 of them.
 __device__ __forceinline__ L2 l2_of_clean_piece(const PieceMasks &m, const PiecePack &pk, uint32_t nb, uint32_t ls_in, uint32_t km1) {
     if (nb == 0) return l2_identity();

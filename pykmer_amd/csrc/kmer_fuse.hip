@@ -43,15 +43,6 @@ __device__ __forceinline__ uint32_t smear_up(uint32_t x, uint32_t n) {
     return acc;
 }
 
-template <typename T>
-__device__ __forceinline__ T wave_shr1(T v, T fill) {                   // lane l gets lane l-1's value, lane 0 gets `fill`
-    if (sizeof(T) == 4) return (T)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)fill, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)((unsigned long long)fill >> 32),
-                                                              (int)(uint32_t)((unsigned long long)v >> 32), 0x138, 0xf, 0xf, false);
-    return (T)(((unsigned long long)hi << 32) | lo);
-}
-
 // NT threads, PER bases each (NT * PER = 16384 = one slot); NB = LDS room for level-1 digits; HS = hot-key slots.
 // COUNT: tally only -- `tally` counters in LDS ([n_tally], the final-bucket digit where there are two levels and
 // <= 2^14 final buckets, the level-1 digit otherwise), written out as one row per workgroup.

@@ -190,13 +190,16 @@ __global__ __launch_bounds__(NT, 4) void k_scatter2(const uint32_t *__restrict__
 // LDS dword; a bucket with more than 65024 records is folded in pieces with a clamp between them so a
 // counter (<= 255 + 65024) can never carry into its neighbour.
 constexpr uint32_t K6_PIECE = 65024;   // multiple of 8
+constexpr uint32_t HIST_REPLICAS = 64; // copies of the 256-bin histogram delta the bucket-count workgroups add into
 
 // `fresh` = first feed after a reset: the table holds nothing yet (it is not even zeroed), so slices
 // are not read back and buckets without records are written as zeros.
 //
 // The value histogram behind Header.update_stats (tools.py:246-263) is maintained here as well: each
-// workgroup writes the net change it made as one row of 256 signed counters, k_hist_reduce adds the
-// rows to the running histogram, and finish() needs no pass over the table (3.3 ms at k=17).  Two ways
+// workgroup adds the net change it made (256 signed counters, a handful of them non-zero) into one of
+// HIST_REPLICAS copies in HBM, k_hist_reduce adds the copies to the running histogram, and finish() needs no
+// pass over the table (3.3 ms at k=17).  (Until late in round 2 every workgroup wrote its own row of 256: 0.5 GB
+// written and read again at k=17.)  Two ways
 // of getting that change, chosen per bucket:
 //   sparse bucket (records < addresses/4, the k=17 case): from the record side -- the LDS add returns
 //     the counter's previous value, so every add knows which bins it moves a k-mer between; counters
@@ -257,7 +260,7 @@ struct SliceTally {
 template <int T, bool LEAN>
 __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
                                                   const uint32_t *__restrict__ final_end, uint32_t fb_bits, uint32_t split_bits,
-                                                  uint8_t *__restrict__ table8, uint32_t fresh, int *__restrict__ bucket_hist, uint8_t *smem,
+                                                  uint8_t *__restrict__ table8, uint32_t fresh, unsigned long long *__restrict__ hist_rep, uint8_t *smem,
                                                   int *dh) {
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);                  // 2^fb_bits / 2 dwords
     const uint32_t fb = blockIdx.x >> split_bits, part = blockIdx.x & ((1u << split_bits) - 1u);
@@ -271,7 +274,6 @@ __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ r
             if (n_addr >= 16) for (uint32_t g = threadIdx.x; g < n_addr / 16; g += T) reinterpret_cast<uint4 *>(slice)[g] = make_uint4(0, 0, 0, 0);
             else for (uint32_t a = threadIdx.x; a < n_addr; a += T) slice[a] = 0;
         }
-        for (uint32_t i = threadIdx.x; i < 256; i += T) bucket_hist[(uint64_t)blockIdx.x * 256 + i] = 0;   // no change to the histogram
         return;                                                          // otherwise the slice stays as it is
     }
     // the first 16 bytes of records every lane will need are requested before the counters are set up, so the
@@ -435,7 +437,11 @@ __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ r
         if (d2) atomicAdd(&dh[2], d2);
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 256; i += T) bucket_hist[(uint64_t)blockIdx.x * 256 + i] = dh[i];
+    // the net change goes to one of HIST_REPLICAS copies of the 256 bins (a handful of non-zero bins per workgroup)
+    for (uint32_t i = threadIdx.x; i < 256; i += T) {
+        const int v = dh[i];
+        if (v) atomicAdd(&hist_rep[(uint64_t)(blockIdx.x % HIST_REPLICAS) * 256 + i], (unsigned long long)(long long)v);
+    }
 }
 
 // Two entry points for the same body.  A whole bucket (dense tables) needs all 128 KiB of LDS a workgroup may
@@ -444,50 +450,42 @@ __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ r
 template <int T>
 __global__ __launch_bounds__(T) void k_bucket_count(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
                                                     const uint32_t *__restrict__ final_end, uint32_t fb_bits, uint32_t split_bits,
-                                                    uint8_t *__restrict__ table8, uint32_t fresh, int *__restrict__ bucket_hist,
+                                                    uint8_t *__restrict__ table8, uint32_t fresh, unsigned long long *__restrict__ hist_rep,
                                                     const uint32_t *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int dh[256];
     if (flags[0]) return;
-    bucket_count_body<T, true>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, bucket_hist, smem, dh);
+    bucket_count_body<T, true>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, hist_rep, smem, dh);
 }
 template <int T>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_bucket_count_half(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start, const uint32_t *__restrict__ final_end,
-                         uint32_t fb_bits, uint32_t split_bits, uint8_t *__restrict__ table8, uint32_t fresh, int *__restrict__ bucket_hist,
+                         uint32_t fb_bits, uint32_t split_bits, uint8_t *__restrict__ table8, uint32_t fresh, unsigned long long *__restrict__ hist_rep,
                          const uint32_t *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int dh[256];
     if (flags[0]) return;
-    bucket_count_body<T, false>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, bucket_hist, smem, dh);
+    bucket_count_body<T, false>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, hist_rep, smem, dh);
 }
 
 template <int T>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_bucket_count_half_lean(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start, const uint32_t *__restrict__ final_end,
-                              uint32_t fb_bits, uint32_t split_bits, uint8_t *__restrict__ table8, uint32_t fresh, int *__restrict__ bucket_hist,
+                              uint32_t fb_bits, uint32_t split_bits, uint8_t *__restrict__ table8, uint32_t fresh, unsigned long long *__restrict__ hist_rep,
                               const uint32_t *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int dh[256];
     if (flags[0]) return;
-    bucket_count_body<T, true>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, bucket_hist, smem, dh);
+    bucket_count_body<T, true>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, hist_rep, smem, dh);
 }
 
 // sums the per-bucket histogram rows into the running 256-bin histogram (signed deltas: two's complement adds)
-__global__ __launch_bounds__(256) void k_hist_reduce(const int *__restrict__ bucket_hist, uint32_t n_rows, unsigned long long *__restrict__ hist,
+__global__ __launch_bounds__(256) void k_hist_reduce(const unsigned long long *__restrict__ hist_rep, unsigned long long *__restrict__ hist,
                                                      const uint32_t *__restrict__ flags) {
     if (flags[0]) return;
-    long long acc = 0;
-    uint32_t r = blockIdx.x;
-    for (; r + 7 * gridDim.x < n_rows; r += 8 * gridDim.x) {             // eight independent row loads in flight
-        int v[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = bucket_hist[(uint64_t)(r + q * gridDim.x) * 256 + threadIdx.x];
-#pragma unroll
-        for (int q = 0; q < 8; q++) acc += v[q];
-    }
-    for (; r < n_rows; r += gridDim.x) acc += bucket_hist[(uint64_t)r * 256 + threadIdx.x];
-    if (acc) atomicAdd(&hist[threadIdx.x], (unsigned long long)acc);
+    unsigned long long acc = 0;                                          // signed deltas: two's complement adds
+    for (uint32_t r = 0; r < HIST_REPLICAS; r++) acc += hist_rep[(uint64_t)r * 256 + threadIdx.x];
+    if (acc) atomicAdd(&hist[threadIdx.x], acc);
 }
 
 // ------------------------------------------------------------------ K7: fold the side list in ---
@@ -625,7 +623,7 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
     lay->side_cap = n_bytes + 16;                          // every side entry stands for >= 1 k-mer
     lay->side = o; o += up((size_t)lay->side_cap * 8);
     lay->side_n = o; o += 256;                             // side-list length (u64), then the flags word
-    lay->bucket_hist = o; o += up((size_t)nfb * 2 * 256 * 4);              // up to 2 workgroups per bucket
+    lay->bucket_hist = o; o += up((size_t)HIST_REPLICAS * 256 * 8);         // replicated histogram deltas of one feed
     return o;
 }
 
@@ -688,12 +686,10 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     const uint32_t split = sparse ? 1u : 0u;
     const size_t part_addrs = (size_t)1 << (pl.fb_bits - split);
     const size_t lds6 = part_addrs * 2 < 64 ? 64 : part_addrs * 2;
-    int *bucket_hist = (int *)(ws + lay.bucket_hist);
+    unsigned long long *bucket_hist = (unsigned long long *)(ws + lay.bucket_hist);
     const uint32_t n_rows6 = (uint32_t)(nfb << split);
-    // bucket_hist holds one row of 256 deltas per workgroup and is sized for two workgroups per bucket
-    // (part_workspace_bytes).  A round-1 experiment with four and eight workgroups per bucket wrote rows past it -- the
-    // abort in gpurun_out/t_sp2.log (small feeds at k=11: the workspace is tiny, so the overrun left the allocation at once).
-    if ((uint64_t)n_rows6 > (uint64_t)nfb * 2) return -3;
+    if (split > 1u) return -3;                                           // the kernels are laid out for whole and half buckets
+    if (hipMemsetAsync(bucket_hist, 0, (size_t)HIST_REPLICAS * 256 * 8, s) != hipSuccess) return -2;
     if (pl.fb_bits == 15)                                                // 64 KiB of counters: two workgroups per CU
         hipLaunchKernelGGL(k_bucket_count_half_lean<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, k6_start, k6_end, pl.fb_bits, split, table8,
                            fresh ? 1u : 0u, bucket_hist, (const uint32_t *)flags);
@@ -703,8 +699,7 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     else
         hipLaunchKernelGGL(k_bucket_count<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, k6_start, k6_end, pl.fb_bits, split, table8,
                            fresh ? 1u : 0u, bucket_hist, (const uint32_t *)flags);
-    hipLaunchKernelGGL(k_hist_reduce, dim3(n_rows6 < 16u ? 1u : (n_rows6 / 16u > 2048u ? 2048u : n_rows6 / 16u)), dim3(256), 0, s, (const int *)bucket_hist,
-                       n_rows6, hist, (const uint32_t *)flags);
+    hipLaunchKernelGGL(k_hist_reduce, dim3(1), dim3(256), 0, s, (const unsigned long long *)bucket_hist, hist, (const uint32_t *)flags);
     hipLaunchKernelGGL(k_apply_side, dim3(AS_WGS), dim3(WG), 0, s, side, side_n, lay.side_cap, table8, hist, (const uint32_t *)flags);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
