@@ -105,12 +105,13 @@ __device__ __forceinline__ L2 l2_compose(const L2 &a, const L2 &b, uint32_t km1)
 // the byte-wise machine.  8 bytes per 64-byte piece: the squeeze pass forms no k-mers, so the carried bases are left out
 // (kmer_fuse.hip takes the bases in front of a slot from the CHUNK's state).
 struct LaneState {
-    uint32_t flags;     // L2 flags (incl. the run length) | ls_in << 16 | dirty << 18
+    uint32_t flags;     // L2 flags (incl. the run length) | ls_in << 16 | dirty << 18 | header piece << 19
     uint32_t rec_tail;  // records opened before the lane, within the chunk (<= 8192) | pending blanks << 16 (<= 16384)
 };
-__device__ __forceinline__ LaneState lane_state_pack(const L2 &rel, uint32_t ls_in, bool dirty) {
+// dirty: the piece needs the byte-wise machine; header piece: it holds header text but the mask path understands it
+__device__ __forceinline__ LaneState lane_state_pack(const L2 &rel, uint32_t ls_in, bool dirty, bool header_piece) {
     LaneState o;
-    o.flags = rel.flags | (ls_in << 16) | (dirty ? (1u << 18) : 0u);
+    o.flags = rel.flags | (ls_in << 16) | (dirty ? (1u << 18) : 0u) | (header_piece ? (1u << 19) : 0u);
     o.rec_tail = rel.rec | ((uint32_t)rel.p_tail << 16);
     return o;
 }
@@ -119,6 +120,7 @@ __device__ __forceinline__ L2 lane_state_l2(const LaneState &o) {
 }
 __device__ __forceinline__ uint32_t lane_state_ls(const LaneState &o) { return (o.flags >> 16) & 3u; }
 __device__ __forceinline__ bool lane_state_dirty(const LaneState &o) { return (o.flags >> 18) & 1u; }
+__device__ __forceinline__ bool lane_state_header_piece(const LaneState &o) { return (o.flags >> 19) & 1u; }
 
 // ---- wave / workgroup exclusive scans (64-wide wavefronts, non-commutative operator) ----------
 __device__ __forceinline__ L1 wave_incl_scan_l1(L1 v, int lane) {
@@ -348,15 +350,18 @@ __device__ __forceinline__ uint32_t movemask4(uint32_t flags80) {       // 0x80-
     return (flags80 * 0x00204081u) >> 28;
 }
 
-// What classify_piece finds in the piece's nb bytes (byte i <-> bit i); bytes past nb count as terminators.
+// What piece_scan finds in the piece's nb bytes (byte i <-> bit i); bytes past nb count as terminators.
 struct PieceMasks {
-    unsigned long long term, valid, bad;   // line terminator; ACGTacgt; needs the byte-wise machine (blank / control byte that is no terminator, or '>')
+    unsigned long long term, valid;    // line terminator; ACGTacgt
+    unsigned long long blank, gt;      // blank or control byte that is no terminator (below 0x21); '>'
 };
 
-// `mine`: the piece's 64 bytes (16-byte aligned).  All lanes of the wave call it together.
-__device__ __forceinline__ void classify_piece(const uint8_t *mine, uint32_t nb, PieceMasks &m, PiecePack &pk) {
+// `mine`: the piece's 64 bytes (16-byte aligned).  All lanes of the wave call it together.  cw: the 2-bit code of every
+// byte (byte i -> bits 2i of the 128 bits), meaningful where `valid` is set.
+__device__ __forceinline__ void piece_scan(const uint8_t *mine, uint32_t nb, PieceMasks &m, uint32_t (&cw)[4]) {
     const uint4 *quads = reinterpret_cast<const uint4 *>(mine);
-    uint32_t vm[2] = {0, 0}, cw[4] = {0, 0, 0, 0};                     // valid bases, codes (byte i -> bits 2i)
+    uint32_t vm[2] = {0, 0};
+    cw[0] = cw[1] = cw[2] = cw[3] = 0;
 #pragma unroll
     for (int q = 0; q < PIECE / 16; q++) {
         const uint4 v = quads[q];
@@ -381,9 +386,9 @@ __device__ __forceinline__ void classify_piece(const uint8_t *mine, uint32_t nb,
     const unsigned long long V = ((((unsigned long long)vm[1]) << 32) | vm[0]) & in_range;
     // everything that is no base -- in plain sequence text one line terminator per piece -- is looked at byte by byte;
     // a wave that holds a piece with many of them (a run of N, a header) tests all bytes four at a time instead
-    unsigned long long T = ~in_range, bad = 0, todo = ~V & in_range;
+    unsigned long long T = ~in_range, blank = 0, gt = 0, todo = ~V & in_range;
     if (__any(__popcll(todo) > 6)) {
-        uint32_t tm[2] = {0, 0}, bm[2] = {0, 0};
+        uint32_t tm[2] = {0, 0}, bm[2] = {0, 0}, gm[2] = {0, 0};
 #pragma unroll
         for (int q = 0; q < PIECE / 16; q++) {
             const uint4 v = quads[q];
@@ -392,13 +397,14 @@ __device__ __forceinline__ void classify_piece(const uint8_t *mine, uint32_t nb,
             for (int j = 0; j < 4; j++) {
                 const int d = q * 4 + j;
                 const uint32_t t = swar_zero(w4[j] ^ 0x0a0a0a0au) | swar_zero(w4[j] ^ 0x0d0d0d0du);
-                const uint32_t bd = (swar_less(w4[j], 0x21212121u) & ~t) | swar_zero(w4[j] ^ 0x3e3e3e3eu);
                 tm[d >> 3] |= movemask4(t) << (4 * (d & 7));
-                bm[d >> 3] |= movemask4(bd) << (4 * (d & 7));
+                bm[d >> 3] |= movemask4(swar_less(w4[j], 0x21212121u) & ~t) << (4 * (d & 7));
+                gm[d >> 3] |= movemask4(swar_zero(w4[j] ^ 0x3e3e3e3eu)) << (4 * (d & 7));
             }
         }
         T |= ((((unsigned long long)tm[1]) << 32) | tm[0]) & in_range;
-        bad = ((((unsigned long long)bm[1]) << 32) | bm[0]) & in_range;
+        blank = ((((unsigned long long)bm[1]) << 32) | bm[0]) & in_range;
+        gt = ((((unsigned long long)gm[1]) << 32) | gm[0]) & in_range;
     } else {
         while (__any(todo != 0ull)) {
             if (todo) {
@@ -406,21 +412,25 @@ __device__ __forceinline__ void classify_piece(const uint8_t *mine, uint32_t nb,
                 const uint32_t c = mine[p];
                 const unsigned long long bit = 1ull << p;
                 if (is_term(c)) T |= bit;
-                else if (c < 0x21u || c == '>') bad |= bit;
+                else if (c < 0x21u) blank |= bit;
+                else if (c == '>') gt |= bit;
                 todo &= todo - 1ull;
             }
         }
     }
-    m.term = T; m.valid = V; m.bad = bad;
-    const unsigned long long S = ~T;                                      // sequence characters, valid or not (a clean piece has nothing else)
-    const unsigned long long none = S & ~V;                               // characters that map to None
-    // restart flags: carry from every None position through the non-base positions above it into the next base
+    m.term = T; m.valid = V; m.blank = blank; m.gt = gt;
+}
+
+// Pushes the bases `V` of a piece together and derives their restart bits.  `none`: the positions that break the run
+// (characters that map to None; header text); everything that is not in V is a hole.  compact = false leaves the codes as
+// they are (a piece whose pack nobody will read: header text is mostly holes).
+__device__ __forceinline__ void piece_compact(unsigned long long V, unsigned long long none, const uint32_t (&cw)[4], bool compact,
+                                              uint32_t n_seq, bool first_is_seq, PiecePack &pk) {
+    // restart flags: carry from every breaking position through the non-base positions above it into the next base
     unsigned long long F = ((~V) + none) & V;
     const uint32_t nv = (uint32_t)__popcll(V);
-    // push the bases together: delete the non-base positions below the highest base, one at a time
     unsigned long long c_lo = ((unsigned long long)cw[1] << 32) | cw[0], c_hi = ((unsigned long long)cw[3] << 32) | cw[2];
-    // (not in a piece that goes to the byte-wise machine anyway: header text is mostly holes)
-    unsigned long long holes = (V && !bad) ? (~V & ((1ull << (63 - __builtin_clzll(V))) - 1ull)) : 0ull;
+    unsigned long long holes = (V && compact) ? (~V & ((1ull << (63 - __builtin_clzll(V))) - 1ull)) : 0ull;   // below the highest base only
     // A whole RUN of neighbouring holes goes at once (the Ns before the first base after a gap: up to 63 positions,
     // which one-at-a-time deletion turned into 63 rounds for the whole wave -- 0.3 ms of the structure pass on a genome
     // with 3 % N).  Plain text has one line terminator per piece, now and then two: two deletions are laid out straight
@@ -452,24 +462,64 @@ __device__ __forceinline__ void classify_piece(const uint8_t *mine, uint32_t nb,
     if (nv < 32u) { c_lo &= (1ull << (2u * nv)) - 1ull; c_hi = 0; }
     else if (nv < 64u) c_hi &= (1ull << (2u * (nv - 32u))) - 1ull;
     pk.c_lo = c_lo; pk.c_hi = c_hi; pk.restart = F;
-    pk.meta = nv | ((uint32_t)__popcll(S) << 8) | ((uint32_t)(S & 1ull) << 16);
+    pk.meta = nv | (n_seq << 8) | ((first_is_seq ? 1u : 0u) << 16);
     pk.pad_ = 0;
 }
 
-// L2 summary of a clean piece from its masks and pack (round 1 read the piece's tail backwards, byte by byte):
-// the valid bases after the last character that maps to None, up to k-1 of them.
-__device__ __forceinline__ L2 l2_of_clean_piece(const PieceMasks &m, const PiecePack &pk, uint32_t nb, uint32_t ls_in, uint32_t km1) {
+// the pack of a piece read as plain sequence text: everything that is no terminator is a sequence character
+__device__ __forceinline__ void classify_piece(const uint8_t *mine, uint32_t nb, PieceMasks &m, PiecePack &pk) {
+    uint32_t cw[4];
+    piece_scan(mine, nb, m, cw);
+    const unsigned long long S = ~m.term;
+    piece_compact(m.valid, S & ~m.valid, cw, (m.blank | m.gt) == 0ull, (uint32_t)__popcll(S), (S & 1ull) != 0ull, pk);
+}
+
+// Header lines by masks.  In a piece whose lines do not begin with a blank or control byte, a line is a header line exactly
+// if its first byte is '>' (indexer.py:66: strip() has nothing to strip in front); the line the piece starts in is one if the
+// piece is entered in state HEADER, or at a line start with '>' first.  Header text = from there up to the line's
+// terminator: adding the start bits into the mask of non-terminators ripples a carry through exactly that stretch.
+__device__ __forceinline__ unsigned long long header_starts(const PieceMasks &m, uint32_t ls_in) {       // '>' that open a record
+    return ((m.term << 1) | (ls_in == LS_START ? 1ull : 0ull)) & m.gt;
+}
+__device__ __forceinline__ unsigned long long header_text(const PieceMasks &m, uint32_t ls_in) {
+    const unsigned long long starts = header_starts(m, ls_in) | (ls_in == LS_HEADER ? 1ull : 0ull);
+    const unsigned long long x = ~m.term;
+    return ((x + starts) ^ x) & x;
+}
+// no line of the piece begins with a blank or control byte (then the L1 summary needs no byte-wise walk)
+__device__ __forceinline__ bool lines_start_plain(const PieceMasks &m) { return (((m.term << 1) | 1ull) & m.blank) == 0ull; }
+
+// L1 summary from the masks of a FULL piece with lines_start_plain(): the state after the last terminator is START; what
+// follows it is a header line if it begins with '>' and sequence text otherwise; blanks further in change nothing.
+__device__ __forceinline__ L1 l1_of_piece(const PieceMasks &m) {
+    const unsigned long long T = m.term;
+    uint32_t kind;
+    if (T) {
+        const uint32_t last = 63u - (uint32_t)__builtin_clzll(T);
+        kind = last == 63u ? (uint32_t)LS_START : (((m.gt >> (last + 1u)) & 1ull) ? (uint32_t)LS_HEADER : (uint32_t)LS_SEQ);
+    } else {
+        kind = (m.gt & 1ull) ? (uint32_t)LS_HEADER : (uint32_t)LS_SEQ;   // what START becomes; HEADER and SEQ pass through
+    }
+    return l1_make(T != 0ull, kind);
+}
+
+// L2 summary from masks: `valid` the bases that count, `brk` the positions that break the run (None characters, header
+// text), `seq` the sequence characters, `n_hdr` record headers opened; pk = piece_compact(valid, brk).  What the byte-wise
+// walk (piece_l2_at) finds for a piece without blanks outside header text.
+__device__ __forceinline__ L2 l2_of_masks(unsigned long long term, unsigned long long valid, unsigned long long brk, unsigned long long seq,
+                                          uint32_t n_hdr, const PiecePack &pk, uint32_t nb, uint32_t ls_in, uint32_t km1) {
     if (nb == 0) return l2_identity();
-    const unsigned long long none = ~m.term & ~m.valid;
+    const unsigned long long in_range = nb >= 64u ? ~0ull : ((1ull << nb) - 1ull);
     const uint32_t nv = pack_n_valid(pk);
     uint32_t tail = nv;
-    if (none) {
-        const uint32_t hb = 63u - (uint32_t)__builtin_clzll(none);
-        tail = hb == 63u ? 0u : (uint32_t)__popcll(m.valid >> (hb + 1u));
+    if (brk) {
+        const uint32_t hb = 63u - (uint32_t)__builtin_clzll(brk);
+        tail = hb == 63u ? 0u : (uint32_t)__popcll(valid >> (hb + 1u));
     }
-    uint32_t flags = F_NONID | F_PRESET;
-    if (ls_in == LS_SEQ && !(m.term & 1ull)) flags |= F_FRONT;
-    if (none || tail >= km1) flags |= F_BRK;
+    uint32_t flags = F_NONID;
+    if ((term & in_range) | seq) flags |= F_PRESET;                      // a terminator or a sequence character zeroes pending blanks
+    if (ls_in == LS_SEQ && (seq & 1ull)) flags |= F_FRONT;
+    if (brk || tail >= km1) flags |= F_BRK;
     const uint32_t len = tail < km1 ? tail : km1;
     const uint32_t n16 = len < 16u ? len : 16u;                          // 32 bits hold the newest 16
     uint32_t bits = 0;
@@ -481,8 +531,13 @@ __device__ __forceinline__ L2 l2_of_clean_piece(const PieceMasks &m, const Piece
         if (n16 < 16u) x32 &= (1u << (2u * n16)) - 1u;
         bits = revpairs32(x32) >> (32u - 2u * n16);                      // newest base lowest
     }
-    L2 s; s.flags = flags | (len << 8); s.bits = bits; s.rec = 0; s.p_tail = 0;
+    L2 s; s.flags = flags | (len << 8); s.bits = bits; s.rec = n_hdr; s.p_tail = 0;
     return s;
+}
+// a clean piece (plain sequence text, not entered inside a header line)
+__device__ __forceinline__ L2 l2_of_clean_piece(const PieceMasks &m, const PiecePack &pk, uint32_t nb, uint32_t ls_in, uint32_t km1) {
+    const unsigned long long seq = ~m.term;
+    return l2_of_masks(m.term, m.valid, seq & ~m.valid, seq, 0u, pk, nb, ls_in, km1);
 }
 
 }  // namespace pk

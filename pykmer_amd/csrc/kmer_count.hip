@@ -83,28 +83,35 @@ __global__ __launch_bounds__(WG, 6) void k_chunk_l2(const uint8_t *__restrict__ 
     __shared__ L1 sh1[WG / 64];
     __shared__ L2 sh2[WG / 64];
     __shared__ uint16_t queue[WG];
-    __shared__ uint32_t n_queued[2];
+    __shared__ uint32_t n_queued[2], n_header_pieces;
     __shared__ uint32_t res1[WG];                          // queued pieces: L1 summary | dirty << 8
     __shared__ uint8_t ls_of[WG];                          // every piece's incoming line state (for the L2 pass over the queue)
     const uint64_t base = (uint64_t)blockIdx.x * CHUNK;
     if (threadIdx.x < 2) n_queued[threadIdx.x] = 0;
+    if (threadIdx.x == 2) n_header_pieces = 0;
     stage_chunk(fasta, base, n_bytes, lds);
     __syncthreads();
     const uint32_t nb = piece_len(base, n_bytes);
     const uint8_t *mine = lds + threadIdx.x * LDS_STRIDE;
     PieceMasks pm;
     PiecePack pk;
-    classify_piece(mine, nb, pm, pk);
+    uint32_t cw[4];
+    piece_scan(mine, nb, pm, cw);
+    const bool full = nb == (uint32_t)PIECE;
+    const bool plain = (pm.blank | pm.gt) == 0ull;                       // nothing but sequence characters and terminators
     {
+        const unsigned long long S = ~pm.term;                           // the pack of the piece read as plain sequence text
+        piece_compact(pm.valid, S & ~pm.valid, cw, plain, (uint32_t)__popcll(S), (S & 1ull) != 0ull, pk);
         uint4 *dst = reinterpret_cast<uint4 *>(packs + (uint64_t)blockIdx.x * WG + threadIdx.x);
         dst[0] = make_uint4((uint32_t)pk.c_lo, (uint32_t)(pk.c_lo >> 32), (uint32_t)pk.c_hi, (uint32_t)(pk.c_hi >> 32));
         dst[1] = make_uint4((uint32_t)pk.restart, (uint32_t)(pk.restart >> 32), pk.meta, 0u);
     }
-    // ---- L1: line state.  Full pieces of plain text from the masks; the rest (and partial pieces) go to the queue
-    const bool full = nb == (uint32_t)PIECE;
-    bool dirty = pm.bad != 0ull;
-    L1 my1 = l1_make(pm.term != 0ull, (pm.term >> 63) ? (uint32_t)LS_START : (uint32_t)LS_SEQ);    // not used if queued
-    const bool q1 = !full || dirty;
+    // ---- L1: line state.  Full pieces whose lines do not begin with a blank from the masks; the rest (and partial pieces)
+    // go to the queue
+    const bool masks1 = full && lines_start_plain(pm);
+    L1 my1 = l1_of_piece(pm);                                            // not used if queued
+    bool dirty = !plain;                                                 // for queued pieces: what the byte-wise walk says
+    const bool q1 = !masks1;
     if (q1) queue[atomicAdd(&n_queued[0], 1u)] = (uint16_t)threadIdx.x;
     __syncthreads();
     for (uint32_t q0 = (threadIdx.x >> 6) * 64u; q0 < n_queued[0]; q0 += WG) {       // wave-uniform
@@ -121,11 +128,28 @@ __global__ __launch_bounds__(WG, 6) void k_chunk_l2(const uint8_t *__restrict__ 
     const L1 st1 = wg_excl_scan_l1(my1, chunk_l1_state[blockIdx.x], sh1, &tot1);
     const uint32_t ls_in = l1_kind(st1);
     ls_of[threadIdx.x] = (uint8_t)ls_in;
-    // ---- L2: record / run state.  Clean pieces from their masks; the rest through the queue again
+    // ---- L2: record / run state.  Clean pieces and header pieces from their masks; the rest through the queue again
     const bool clean = !dirty && ls_in != LS_HEADER;
+    // a header piece: header lines by masks (header_text), and no blank or control byte outside header text
+    bool header_piece = false;
+    unsigned long long H = 0;
+    if (__any(!clean && masks1)) {
+        H = header_text(pm, ls_in);
+        header_piece = !clean && masks1 && (pm.blank & ~H) == 0ull;
+    }
     L2 my2 = l2_identity();
     if (clean) my2 = l2_of_clean_piece(pm, pk, nb, ls_in, km1);
-    else queue[atomicAdd(&n_queued[1], 1u)] = (uint16_t)threadIdx.x;      // the L1 queue was consumed before the scan's barriers
+    if (__any(header_piece)) {                                           // compaction again, without the header text
+        const unsigned long long seq = ~pm.term & ~H, valid = pm.valid & seq;
+        PiecePack hk;
+        piece_compact(header_piece ? valid : 0ull, header_piece ? ((seq & ~valid) | H) : 0ull, cw, true, 0u, false, hk);
+        if (header_piece)
+            my2 = l2_of_masks(pm.term, valid, (seq & ~valid) | H, seq, (uint32_t)__popcll(header_starts(pm, ls_in)), hk, nb, ls_in, km1);
+    }
+    const bool q2 = !clean && !header_piece;
+    if (q2) queue[atomicAdd(&n_queued[1], 1u)] = (uint16_t)threadIdx.x;   // the L1 queue was consumed before the scan's barriers
+    const unsigned long long hp_wave = __ballot(header_piece);
+    if ((threadIdx.x & 63u) == 0u && hp_wave) atomicAdd(&n_header_pieces, (uint32_t)__popcll(hp_wave));
     __syncthreads();
     for (uint32_t q0 = (threadIdx.x >> 6) * 64u; q0 < n_queued[1]; q0 += WG) {
         const uint32_t qi = q0 + (threadIdx.x & 63u);
@@ -138,16 +162,16 @@ __global__ __launch_bounds__(WG, 6) void k_chunk_l2(const uint8_t *__restrict__ 
         }
     }
     __syncthreads();
-    if (!clean) {
+    if (q2) {
         const uint32_t *in = reinterpret_cast<const uint32_t *>(mine);
         my2.flags = in[0]; my2.bits = in[1]; my2.rec = in[2]; my2.p_tail = in[3];
     }
     L2 total;
     const L2 rel = wg_excl_scan_l2(my2, l2_identity(), sh2, &total, km1);     // prefix relative to the chunk start
-    lane_state[(uint64_t)blockIdx.x * WG + threadIdx.x] = lane_state_pack(rel, ls_in, dirty);
+    lane_state[(uint64_t)blockIdx.x * WG + threadIdx.x] = lane_state_pack(rel, ls_in, q2, header_piece);
     if (threadIdx.x == 0) {
         chunk_l2[blockIdx.x] = total;
-        chunk_odd[blockIdx.x] = n_queued[1];               // pieces that are not plain sequence text: the squeeze pass queues them too
+        chunk_odd[blockIdx.x] = n_queued[1] + n_header_pieces;   // pieces whose text the squeeze pass has to see
     }
 }
 

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(WG, 4) void k_squeeze(const uint8_t *__restrict__ f
         // control byte need the byte-wise machine, which costs the same for one lane as for 64: they are queued, and the
         // queue is worked off 64 pieces per wave pass -- with a header every kilobase (read sets) that is one pass per
         // workgroup instead of one per wave.  A queued piece's result is left in the piece's own 64 bytes of the image.
-        const bool clean = !lane_state_dirty(lst) && ls_in != LS_HEADER;             // the structure pass's definition: chunk_odd counts the rest
+        const bool clean = !lane_state_dirty(lst) && !lane_state_header_piece(lst) && ls_in != LS_HEADER;   // the structure pass's definition: chunk_odd counts the rest
         {
             PiecePack pk;
             pk.c_lo = ((unsigned long long)me.p0.y << 32) | me.p0.x; pk.c_hi = ((unsigned long long)me.p0.w << 32) | me.p0.z;
