@@ -667,7 +667,8 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     const uint32_t *k6_start = bucket_base, *k6_end = bucket_end;        // b2 == 0: the level-1 buckets are the final ones
     if (laid_out2) {
         static const uint32_t xcd_affine = getenv("PK_XCD") ? (uint32_t)atoi(getenv("PK_XCD")) : 1u;
-        static const uint32_t grid2 = getenv("PK_GRID2") ? (uint32_t)atoi(getenv("PK_GRID2")) : 512u;      // 256 CUs x 2; a multiple of 8
+        static const uint32_t grid2_env = getenv("PK_GRID2") ? (uint32_t)atoi(getenv("PK_GRID2")) : 512u;  // 256 CUs x 2
+        const uint32_t grid2 = grid2_env < 8u ? 8u : (grid2_env & ~7u);    // a multiple of 8: every XCD class gets the same number of workgroups
         hipLaunchKernelGGL((k_scatter2<true, 512, 32>), dim3(grid2), dim3(512), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
                            bucket_base, bucket_end, (const uint32_t *)nullptr, final_start, pl, out2, cursor2, (const uint32_t *)cap2_end,
                            (uint32_t)pl.capacity2, flags, xcd_affine);
