@@ -95,6 +95,103 @@ __global__ __launch_bounds__(512) void k_rows2_scan(const uint32_t *__restrict__
     }
 }
 
+// ---- sample2: final-bucket sizes from a sample of the level-1 records (2^15 < final buckets <= 2^18: k = 17, slices of k = 19).
+// One workgroup per level-1 bucket tallies the level-2 digit of every stride2-th block of 1024 records in LDS (stride2 = 1:
+// all of them, i.e. exact).  Blocks are what tiles of the level-1 sort wrote, so this samples stretches of the text like the
+// slot sample of level 1 does.  It replaces the exact counting pass over ALL level-1 records (k_count2: 0.66 ms at k = 17).
+__global__ __launch_bounds__(1024) void k_sample2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ bucket_base,
+                                                  const uint32_t *__restrict__ bucket_end, PartPlan pl, uint32_t stride2,
+                                                  uint32_t *__restrict__ tally, uint32_t *__restrict__ sampled_n,
+                                                  const uint32_t *__restrict__ flags) {
+    __shared__ uint32_t h[512];
+    __shared__ uint32_t n_seen;
+    if (flags[0]) return;
+    const uint32_t b = blockIdx.x, lo = bucket_base[b], hi = bucket_end[b];
+    if (threadIdx.x < 512) h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) n_seen = 0;
+    __syncthreads();
+    const uint32_t n_blk = (hi - lo + 1023u) / 1024u, mask = pl.B2 - 1u, shift = pl.fb_bits;
+    uint32_t mine = 0;
+    for (uint32_t blk0 = 0; blk0 < n_blk; blk0 += 8u * stride2) {        // eight loads in flight per lane
+        uint32_t v[8];
+        bool ok[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t blk = blk0 + (uint32_t)u * stride2;
+            const uint64_t i = (uint64_t)lo + (uint64_t)blk * 1024u + threadIdx.x;
+            ok[u] = blk < n_blk && i < hi;
+            v[u] = ok[u] ? in[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (ok[u]) { atomicAdd(&h[(v[u] >> shift) & mask], 1u); mine++; }
+    }
+    for (int d = 32; d; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&n_seen, mine);
+    __syncthreads();
+    if (threadIdx.x < pl.B2) tally[(uint64_t)b * pl.B2 + threadIdx.x] = h[threadIdx.x];
+    if (threadIdx.x == 0) sampled_n[b] = n_seen;
+}
+// room of every final bucket (its tally scaled by its level-1 bucket's size / sampled records, + 12.5 % + slack; exact
+// tallies as they are), its start inside its block of 1024 final buckets, the block totals
+__global__ __launch_bounds__(1024) void k_rooms2(const uint32_t *__restrict__ tally, const uint32_t *__restrict__ sampled_n,
+                                                 const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ bucket_end, PartPlan pl,
+                                                 uint32_t stride2, uint32_t n_final, uint32_t *__restrict__ final_start,
+                                                 uint32_t *__restrict__ cap2_end, uint32_t *__restrict__ block_tot, const uint32_t *__restrict__ flags) {
+    __shared__ uint32_t wsum[16];
+    if (flags[0]) return;
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    uint32_t room = 0;
+    if (i < n_final) {
+        const uint32_t b = i >> pl.b2, hcount = tally[i];
+        if (stride2 == 1u) room = hcount;
+        else {
+            const uint32_t seen = sampled_n[b], n_b = bucket_end[b] - bucket_base[b];
+            const unsigned long long est = seen ? (unsigned long long)((double)hcount * ((double)n_b / (double)seen)) + 1ull : 0ull;
+            room = (uint32_t)(est + est / 8 + 4096u);
+        }
+        room = (room + 7u) & ~7u;                                        // 16-bit records: starts stay 16-byte aligned
+    }
+    uint32_t inc = room;                                                 // exclusive scan over the block's 1024 rooms
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t pre = 0, total = 0;
+    for (int j = 0; j < 16; j++) { if (j < w) pre += wsum[j]; total += wsum[j]; }
+    if (i < n_final) { final_start[i] = pre + inc - room; cap2_end[i] = room; }
+    if (threadIdx.x == 0) block_tot[blockIdx.x] = total;
+}
+// block bases (one workgroup: <= 256 blocks), then absolute starts, cursors and limits
+__global__ __launch_bounds__(1024) void k_bases2(uint32_t n_blocks, uint32_t n_final, PartPlan pl, uint32_t *__restrict__ block_tot,
+                                                 uint32_t *__restrict__ final_start, uint32_t *__restrict__ flags) {
+    __shared__ uint32_t wsum[16];
+    if (flags[0]) return;
+    const uint32_t v = threadIdx.x < n_blocks ? block_tot[threadIdx.x] : 0u;
+    uint32_t inc = v;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t pre = 0, total = 0;
+    for (int j = 0; j < 16; j++) { if (j < w) pre += wsum[j]; total += wsum[j]; }
+    if (threadIdx.x < n_blocks) block_tot[threadIdx.x] = pre + inc - v;
+    if (threadIdx.x == 0) {
+        final_start[n_final] = total;
+        if ((uint64_t)total > pl.capacity2) flags[0] = 1u;               // cannot happen with the bounds of make_part_plan; be loud if it does
+    }
+}
+__global__ __launch_bounds__(1024) void k_starts2(uint32_t n_final, const uint32_t *__restrict__ block_base, uint32_t *__restrict__ final_start,
+                                                  uint32_t *__restrict__ cursor2, uint32_t *__restrict__ cap2_end, const uint32_t *__restrict__ flags) {
+    if (flags[0]) return;
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    if (i >= n_final) return;
+    const uint32_t a = block_base[blockIdx.x] + final_start[i];
+    final_start[i] = a; cursor2[i] = a; cap2_end[i] = a + cap2_end[i];
+}
+
 // CLAIM: no precomputed offsets; every tile claims room for its runs from the final buckets' cursors, inside the
 // room k_provision gave each of them (cap_end; a bucket that outgrows it raises flags[0], see part_common.h).  Where
 // a record lands inside its final bucket then depends on timing -- the bucket's contents as a multiset do not.
@@ -585,7 +682,8 @@ PartPlan make_part_plan(uint32_t k, uint64_t n_bytes, uint32_t slice_bits, uint3
     pl.sample_stride = pl.n_chunks >= 1024u ? 16u : 1u;
     const uint64_t nfb = (uint64_t)pl.B1 * pl.B2;
     pl.n_tally = (pl.b2 && nfb <= 32768 && pl.addr_bits <= 30) ? (uint32_t)nfb : pl.B1;
-    if (pl.n_tally > pl.B1) {                              // level 2 claims its room tile by tile: small work items for a persistent grid
+    pl.sample2 = (pl.b2 && pl.n_tally == pl.B1 && nfb <= 262144 && pl.B1 >= 8u) ? 1u : 0u;
+    if (pl.n_tally > pl.B1 || pl.sample2) {                // level 2 claims its room tile by tile: small work items for a persistent grid
         pl.R2 = 4u * TILE;
         pl.n_wg2_max = (uint32_t)(n_bytes / pl.R2) + pl.B1 + 1;
     }
@@ -593,20 +691,20 @@ PartPlan make_part_plan(uint32_t k, uint64_t n_bytes, uint32_t slice_bits, uint3
     // bucket gets 12.5 % + a constant + alignment on top of it (k_provision)
     const uint64_t est1 = (uint64_t)pl.n_chunks * TILE + pl.B1, est2 = (uint64_t)pl.n_chunks * TILE + nfb;
     pl.capacity1 = est1 + est1 / 8 + (uint64_t)pl.B1 * 4100;
-    pl.capacity2 = est2 + est2 / 8 + nfb * 2056;
+    pl.capacity2 = est2 + est2 / 8 + nfb * (pl.sample2 ? 4104 : 2056);
     return pl;
 }
 
 size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace *lay) {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const uint64_t nfb = (uint64_t)pl.B1 * pl.B2;
-    const bool laid_out2 = pl.n_tally > pl.B1;               // final buckets provisioned from the estimate (k <= 15, two levels)
+    const bool laid_out2 = pl.n_tally > pl.B1 || pl.sample2; // final buckets provisioned from an estimate
     size_t o = 0;
     lay->codes = o; o += up((size_t)pl.n_chunks * SLOT_CODE_WORDS * 4);
     lay->restarts = o; o += up((size_t)pl.n_chunks * SLOT_RST_WORDS * 4);
     lay->n_bases = o; o += up((size_t)pl.n_chunks * 4);
     lay->tally_rows = o; o += up((size_t)COUNT_WGS * pl.n_tally * 4);
-    lay->tally_tot = o; o += up((size_t)pl.n_tally * 4);
+    lay->tally_tot = o; o += up(pl.sample2 ? (size_t)nfb * 4 + (size_t)(pl.B1 + 1024) * 4 : (size_t)pl.n_tally * 4);   // sample2: + sampled counts, block totals
     lay->bucket_base = o; o += up((size_t)(pl.B1 + 1) * 4);
     lay->bucket_end = o; o += up((size_t)(pl.B1 + 1) * 4);
     lay->compact_base = o; o += up((size_t)(pl.B1 + 1) * 4);
@@ -654,7 +752,7 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     unsigned long long *side = (unsigned long long *)(ws + lay.side), *side_n = (unsigned long long *)(ws + lay.side_n);
     uint32_t *flags = (uint32_t *)(side_n + 1);
     const uint32_t nfb = pl.B1 * pl.B2;
-    const bool laid_out2 = pl.n_tally > pl.B1;
+    const bool laid_out2 = pl.n_tally > pl.B1 || pl.sample2;
     if (pl.B1 > (pl.k <= 15 ? 128u : 512u) || pl.B2 > 512u || pl.fb_bits > 16u) return -3;   // what the kernels' LDS arrays are sized for
     if (hipMemsetAsync(side_n, 0, 16, s) != hipSuccess) return -2;   // side-list length + flags
     launch_provision(codes, restarts, n_bases, st2, pl, stride, tally_rows, tally_tot, bucket_base, cursor1, cap_end, final_start, cursor2, cap2_end,
@@ -665,6 +763,18 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     if (ev_sort_end) hipEventRecord(ev_sort_end, s);
     const uint16_t *final_recs = (const uint16_t *)out1;
     const uint32_t *k6_start = bucket_base, *k6_end = bucket_end;        // b2 == 0: the level-1 buckets are the final ones
+    if (pl.sample2) {                                                    // final-bucket rooms from a sample of the level-1 records
+        const uint32_t stride2 = stride == 1u ? 1u : 16u, n_blocks = (nfb + 1023u) / 1024u;
+        uint32_t *sampled_n = tally_tot + nfb, *block_tot = sampled_n + pl.B1;
+        hipLaunchKernelGGL(k_sample2, dim3(pl.B1), dim3(1024), 0, s, (const uint32_t *)out1, (const uint32_t *)bucket_base, (const uint32_t *)bucket_end,
+                           pl, stride2, tally_tot, sampled_n, (const uint32_t *)flags);
+        hipLaunchKernelGGL(k_rooms2, dim3(n_blocks), dim3(1024), 0, s, (const uint32_t *)tally_tot, (const uint32_t *)sampled_n,
+                           (const uint32_t *)bucket_base, (const uint32_t *)bucket_end, pl, stride2, nfb, final_start, cap2_end, block_tot,
+                           (const uint32_t *)flags);
+        hipLaunchKernelGGL(k_bases2, dim3(1), dim3(1024), 0, s, n_blocks, nfb, pl, block_tot, final_start, flags);
+        hipLaunchKernelGGL(k_starts2, dim3(n_blocks), dim3(1024), 0, s, nfb, (const uint32_t *)block_tot, final_start, cursor2, cap2_end,
+                           (const uint32_t *)flags);
+    }
     if (laid_out2) {
         static const uint32_t xcd_affine = getenv("PK_XCD") ? (uint32_t)atoi(getenv("PK_XCD")) : 1u;
         static const uint32_t grid2_env = getenv("PK_GRID2") ? (uint32_t)atoi(getenv("PK_GRID2")) : 512u;  // 256 CUs x 2

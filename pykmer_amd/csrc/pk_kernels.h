@@ -52,6 +52,8 @@ struct PartPlan {
     uint32_t sample_stride;  // every how-manieth slot is tallied to size the buckets (1 = all: exact)
     uint32_t n_tally;        // what the sampling launch tallies: B1 * B2 final buckets (both levels are then laid out from
                              // the estimate), or just the B1 level-1 buckets (one level, or too many final buckets: k = 17)
+    uint32_t sample2;        // 1: the final buckets (too many to tally while sampling slots: 2^15 < B1 * B2 <= 2^18) are sized from a
+                             // sample of the level-1 RECORDS, after the level-1 sort, and level 2 claims its room like the others
     uint64_t capacity1;      // record slots for all level-1 buckets together (the dump area starts there)
     uint64_t capacity2;      // the same for the final buckets, where they are laid out from the estimate
 };
