@@ -100,5 +100,27 @@ def make_input(spec: dict) -> bytes:
     return data
 
 
+def skewed_fasta(n_bp: int, unit_len: int, seed: int = 7, chunk: int = 16384, stride: int = 16) -> bytes:
+    """One record whose 16 KiB text chunks number 0, 16, 32, ... hold uniform random sequence while every other chunk
+    repeats one `unit_len`-base unit (a period the hot-key path does not look for).  The indexer sizes its buckets from
+    every `stride`-th chunk: this text makes that estimate wrong by an order of magnitude on purpose, so the buckets
+    overflow and the exact re-layout has to run."""
+    import numpy as np
+    assert n_bp % 60 == 0
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    head = b">skewed_against_the_sample\n"
+    i = np.arange(n_bp, dtype=np.int64)
+    off = len(head) + i + i // 60                              # byte offset of base i: 60 bases and a newline per line
+    unit = acgt[rng.integers(0, 4, size=unit_len)]
+    seq = acgt[rng.integers(0, 4, size=n_bp)]
+    rep = (off // chunk) % stride != 0
+    seq[rep] = unit[i[rep] % unit_len]
+    lines = np.empty((n_bp // 60, 61), dtype=np.uint8)
+    lines[:, :60] = seq.reshape(-1, 60)
+    lines[:, 60] = 10
+    return head + lines.tobytes()
+
+
 def sha256(data) -> str:
     return hashlib.sha256(data).hexdigest()

@@ -347,3 +347,33 @@ def test_many_distinct_tandem_repeats(gpu):
     assert len(data) > 2_000_000
     for k in (9, 15):
         _check_against_oracle(gpu, data, k)
+
+
+@pytest.mark.parametrize("k,unit_len", [(13, 61), (15, 61), (15, 997), (17, 61)])
+def test_bucket_overflow_takes_the_exact_relayout(gpu, k, unit_len):
+    """Bucket rooms come from a sample (every 16th slot of a feed of >= 1024 chunks; k = 17: + a sample of the level-1
+    records).  A text whose sampled chunks look nothing like the rest must overflow them: the overflow flag makes every
+    later kernel of the feed return untouched and the host repeats the passes with exact sizes (`relayouts`; for k = 17
+    that is the counting pass k_count2 / k_rows2_scan).  Second feed on the same indexer: the same against a table that
+    is no longer fresh."""
+    data = inputs.skewed_fasta(20_000_040, unit_len, seed=7 + unit_len)
+    assert len(data) >= 1024 * 16384
+    more = inputs.skewed_fasta(18_000_000, unit_len + 2, seed=11)
+    kmers = np.concatenate([oracle.kmer_list(data, k), oracle.kmer_list(more, k)])
+    u, c = np.unique(kmers, return_counts=True)
+    sat = np.minimum(c, 255).astype(np.uint8)
+    with gpu.Indexer(k) as ix:
+        ix.feed(data)
+        first = ix.timings()["relayouts"]
+        assert first >= 1, "the skewed text was meant to overflow the sampled layout"
+        ix.feed(more)
+        assert ix.timings()["relayouts"] > first
+        fin = ix.finish()
+        assert fin["num_kmers"] == kmers.size
+        h = fin["hist256"]
+        assert int(h.sum()) == 4 ** k
+        assert np.array_equal(h[1:], np.bincount(sat, minlength=256)[1:].astype(np.uint64))
+        table = ix.table_to_host()
+        assert np.array_equal(table[u.astype(np.int64)], sat)
+        step = 1 << 30
+        assert sum(int(np.count_nonzero(table[o:o + step])) for o in range(0, table.size, step)) == u.size
