@@ -187,7 +187,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     acc = {"scan_s": 0.0, "squeeze_s": 0.0, "walk_sort_s": 0.0, "partition_s": 0.0, "bucket_s": 0.0, "finalize_s": 0.0, "zero_s": 0.0}
-    relayouts = 0
+    relayouts = recounted = 0
     fin = None
     for _ in range(args.steps):
         fin = step()
@@ -195,6 +195,7 @@ def main():
         for key in acc:
             acc[key] += t[key]
         relayouts += t["relayouts"]
+        recounted = t["buckets_recounted"]
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -247,7 +248,7 @@ def main():
                      "walk_sort_kernel": avg["walk_sort_s"] * 1e3,
                      "bucket_layout_and_level2": (avg["partition_s"] - avg["walk_sort_s"]) * 1e3,
                      "bucket_count": avg["bucket_s"] * 1e3, "finish": avg["finalize_s"] * 1e3,
-                     "bucket_relayouts": relayouts},
+                     "bucket_relayouts": relayouts, "buckets_recounted_per_step": recounted},
         "t_kernel_s": elapsed / args.steps,
     }
 

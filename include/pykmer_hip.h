@@ -105,7 +105,8 @@ int pk_indexer_table_slice_to_device(pk_indexer *ix, void *dev_dst, uint64_t off
  * [0] structure scans, [1] squeeze pass (text -> packed bases + record tallies), [2] finish, [3] reset,
  * [4] feeds (as a double), [5] everything between squeeze and bucket count (bucket layout, fused k-mer
  * assembly + level-1 sort, level 2), [6] bucket count + histogram rows + side list, [7] of [5]: the fused
- * k_walk_sort kernel alone, [8] how many feeds had to be laid out a second time with exact bucket sizes. */
+ * k_walk_sort kernel alone, [8] how many feeds had to be laid out a second time with exact bucket sizes, [9] how many final buckets of a
+ * sparse table were counted a second time because a byte counter wrapped (k_bucket_count_bytes). */
 int pk_indexer_timings(pk_indexer *ix, double out[10]);
 void pk_indexer_destroy(pk_indexer *ix);
 

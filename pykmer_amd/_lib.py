@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpykmer_hip.so")
+# PK_LIB: another build of the same library (kernel experiments: tools/build_variant.sh); never a CPU stand-in
+LIB_PATH = os.environ.get("PK_LIB") or os.path.join(_HERE, "libpykmer_hip.so")
 
 PK_OK, PK_ERR_ARG, PK_ERR_HIP, PK_ERR_RECS_CAP, PK_ERR_STATE = 0, -1, -2, -3, -4
 
@@ -228,7 +229,7 @@ class Indexer:
         t = np.zeros(10, dtype=np.float64)
         _check(load().pk_indexer_timings(self._h, t.ctypes.data))
         return {"scan_s": t[0], "squeeze_s": t[1], "finalize_s": t[2], "zero_s": t[3], "feeds": int(t[4]),
-                "partition_s": t[5], "bucket_s": t[6], "walk_sort_s": t[7], "relayouts": int(t[8])}
+                "partition_s": t[5], "bucket_s": t[6], "walk_sort_s": t[7], "relayouts": int(t[8]), "buckets_recounted": int(t[9])}
 
 
 def count_fasta(data, k: int, device: int = 0, table_out: np.ndarray = None):

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
             settle();
             continue;
         }
-        scatter_tile<KT, WIDE, NT>(L, r, okm, ~0u, shift, B, low_mask, out16, out, settle, cursor1, cap_end, dump, flags);
+        scatter_tile<KT, WIDE, NT, PER, NB, false, PK_PB_L1, (WIDE ? 0 : PK_SB_L1)>(L, r, okm, ~0u, shift, B, low_mask, out16, out, settle, cursor1, cap_end, dump, flags);
         if (hot.used >= HS / 2) hot_flush(hot, side, side_n, side_cap);   // uniform: read after the barrier that ends the tile
     }
     if (COUNT) {

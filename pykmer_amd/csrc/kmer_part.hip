@@ -255,8 +255,8 @@ __global__ __launch_bounds__(NT, 4) void k_scatter2(const uint32_t *__restrict__
             if (win + TILE < hi) fetch(win + TILE, nxt);
             uint32_t *cl = CLAIM ? cursor + (uint64_t)b * B : nullptr;
             const uint32_t *ce = CLAIM ? cap_end + (uint64_t)b * B : nullptr;
-            if (full) scatter_tile<uint32_t, false, NT, PER, 512, true>(L, r, 0u, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
-            else scatter_tile<uint32_t, false, NT, PER, 512, false>(L, r, okm, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
+            if (full) scatter_tile<uint32_t, false, NT, PER, 512, true, PK_PB_L2, PK_SB_L2>(L, r, 0u, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
+            else scatter_tile<uint32_t, false, NT, PER, 512, false, PK_PB_L2, PK_SB_L2>(L, r, okm, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
         }
     };
     if (!CLAIM) {
@@ -287,6 +287,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter2(const uint32_t *__restrict__
 // LDS dword; a bucket with more than 65024 records is folded in pieces with a clamp between them so a
 // counter (<= 255 + 65024) can never carry into its neighbour.
 constexpr uint32_t K6_PIECE = 65024;   // multiple of 8
+constexpr int K6_BYTES_LDS = 65536 + 1024 + 128;   // k_bucket_count_bytes: slice image, histogram bins, wrap flag
 constexpr uint32_t HIST_REPLICAS = 64; // copies of the 256-bin histogram delta the bucket-count workgroups add into
 
 // `fresh` = first feed after a reset: the table holds nothing yet (it is not even zeroed), so slices
@@ -358,9 +359,9 @@ template <int T, bool LEAN>
 __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
                                                   const uint32_t *__restrict__ final_end, uint32_t fb_bits, uint32_t split_bits,
                                                   uint8_t *__restrict__ table8, uint32_t fresh, unsigned long long *__restrict__ hist_rep, uint8_t *smem,
-                                                  int *dh) {
+                                                  int *dh, uint32_t wg) {
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);                  // 2^fb_bits / 2 dwords
-    const uint32_t fb = blockIdx.x >> split_bits, part = blockIdx.x & ((1u << split_bits) - 1u);
+    const uint32_t fb = wg >> split_bits, part = wg & ((1u << split_bits) - 1u);
     // final buckets lie back to back (end = the next one's start) unless they ARE the provisioned level-1 buckets
     const uint32_t start = final_start[fb], end = final_end ? final_end[fb] : final_start[fb + 1];
     const uint32_t part_bits = fb_bits - split_bits;
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(T) void k_bucket_count(const uint16_t *__restrict__
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int dh[256];
     if (flags[0]) return;
-    bucket_count_body<T, true>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, hist_rep, smem, dh);
+    bucket_count_body<T, true>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, hist_rep, smem, dh, blockIdx.x);
 }
 template <int T>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8)))
@@ -562,7 +563,7 @@ void k_bucket_count_half(const uint16_t *__restrict__ recs, const uint32_t *__re
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int dh[256];
     if (flags[0]) return;
-    bucket_count_body<T, false>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, hist_rep, smem, dh);
+    bucket_count_body<T, false>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, hist_rep, smem, dh, blockIdx.x);
 }
 
 template <int T>
@@ -573,7 +574,107 @@ void k_bucket_count_half_lean(const uint16_t *__restrict__ recs, const uint32_t 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int dh[256];
     if (flags[0]) return;
-    bucket_count_body<T, true>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, hist_rep, smem, dh);
+    bucket_count_body<T, true>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, hist_rep, smem, dh, blockIdx.x);
+}
+
+// Sparse tables (k = 17: ~3000 records per final bucket of 2^16 addresses) -- BYTE counters.  One workgroup per final
+// bucket keeps the bucket's 64 KiB slice of the table in LDS *as it will lie in HBM*: a record adds 1 << 8 * (a & 3) to
+// the dword holding its byte, the add returns the byte's previous value (which is what the histogram needs), and the
+// slice leaves LDS by a straight 16-byte copy -- no 16-bit counters to clamp and pack, no second workgroup reading the
+// same records, half the LDS zeroing per table byte (k_bucket_count_half: two workgroups per bucket, each with 2^15 16-bit
+// counters, each reading all of the bucket's records).
+// A byte cannot saturate: the add that finds 255 wraps it and carries into its neighbour.  That add SEES the 255, so it
+// raises a flag, and the workgroup then throws its LDS image away and counts the bucket again the old way (both halves,
+// one after the other, 16-bit counters with clamping).  Hot k-mers of period <= 3 never get here (side list), so this is
+// the rare bucket that holds a k-mer more than 254 times (or one already saturated by an earlier feed).
+template <int T>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_bucket_count_bytes(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start, const uint32_t *__restrict__ final_end,
+                          uint8_t *__restrict__ table8, uint32_t fresh, unsigned long long *__restrict__ hist_rep,
+                          const uint32_t *__restrict__ flags) {
+    // 64 KiB: the slice, then the 256 histogram bins and the wrap flag.  No static LDS in this kernel: it would sit in
+    // front of the slice, and with the slice's base off a 128-byte line every 16-byte LDS access of the zeroing and the
+    // copy-out ran into bank conflicts (a 4-byte static pushed the base to 1040: 1.5 G conflict cycles per launch against
+    // 0.3 G, 6.6 ms against 5.2 for the kernel this one replaces).
+    extern __shared__ __attribute__((aligned(128))) uint8_t smem[];
+    constexpr uint32_t N_ADDR = 65536u;
+    int *dh = reinterpret_cast<int *>(smem + N_ADDR);
+    uint32_t *wrap_flag = reinterpret_cast<uint32_t *>(smem + N_ADDR + 1024);
+    if (flags[0]) return;
+    const uint32_t fb = blockIdx.x;
+    const uint32_t start = final_start[fb], end = final_end ? final_end[fb] : final_start[fb + 1];
+    uint4 *slice = reinterpret_cast<uint4 *>(table8 + ((uint64_t)fb << 16));
+    uint4 *img = reinterpret_cast<uint4 *>(smem);
+    if (start == end) {
+        if (fresh) for (uint32_t g = threadIdx.x; g < N_ADDR / 16; g += T) slice[g] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    // A bucket with many records is nearly always one hot address (what the period-1..3 test of the level-1 sort let
+    // through of a repeat family): eight unmerged adds per lane on ONE LDS address, only to find the byte wrapped.  Such a
+    // bucket goes to the 16-bit counters at once (they merge equal neighbours and clamp between pieces).
+    bool recount = end - start >= 16384u;                                // uniform
+    int d1 = 0, d2 = 0;
+    if (!recount) {
+        const uint32_t base = start & ~7u;                               // 16-byte aligned vector loads, 8 records per lane
+        const uint32_t i_first = base + threadIdx.x * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i_first < end) v = *reinterpret_cast<const uint4 *>(recs + i_first);
+        for (uint32_t i = threadIdx.x; i < 256; i += T) dh[i] = 0;
+        if (threadIdx.x == 0) *wrap_flag = 0u;
+        if (fresh) { for (uint32_t g = threadIdx.x; g < N_ADDR / 16; g += T) img[g] = make_uint4(0, 0, 0, 0); }
+        else { for (uint32_t g = threadIdx.x; g < N_ADDR / 16; g += T) img[g] = slice[g]; }
+        __syncthreads();
+        uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);
+        bool wrapped = false;
+        for (uint32_t p0 = base; p0 < end; p0 += (uint32_t)T * 8u) {    // at most three rounds
+            const uint32_t i = p0 + threadIdx.x * 8;
+            if (i >= end) continue;                                      // lanes without records stay out of LDS (their adds would all meet on one address)
+            if (p0 != base) v = *reinterpret_cast<const uint4 *>(recs + i);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            const bool interior = i >= start && i + 8u <= end;           // nearly every lane
+            uint32_t old[8];
+            bool in[8];
+            // eight adds back to back (records outside the bucket add zero), their returned bytes looked at afterwards
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t a = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu, sh = 8u * (a & 3u);
+                in[q] = interior || (i + q >= start && i + q < end);
+                old[q] = (atomicAdd(&cnt[a >> 2], in[q] ? (1u << sh) : 0u) >> sh) & 0xffu;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t c = old[q];
+                if (!in[q]) continue;
+                if (c == 0u) d1++;
+                else if (c == 1u) { d2++; d1--; }
+                else if (c == 255u) wrapped = true;
+                else { atomicAdd(&dh[c + 1u], 1); atomicAdd(&dh[c], -1); }
+            }
+        }
+        if (wrapped) *wrap_flag = 1u;
+        __syncthreads();
+        recount = *wrap_flag != 0u;                                      // uniform
+        __syncthreads();                                                 // the bins and counters may be set up again below
+    }
+    if (recount) {
+        // count the bucket with 16-bit counters, one half of the address range after the other
+        if (threadIdx.x == 0) atomicAdd(const_cast<uint32_t *>(&flags[1]), 1u);               // statistics: pk_indexer_timings [9]
+        bucket_count_body<T, false>(recs, final_start, final_end, 16u, 1u, table8, fresh, hist_rep, smem, dh, 2u * fb);
+        __syncthreads();
+        bucket_count_body<T, false>(recs, final_start, final_end, 16u, 1u, table8, fresh, hist_rep, smem, dh, 2u * fb + 1u);
+        return;
+    }
+    for (uint32_t g = threadIdx.x; g < N_ADDR / 16; g += T) slice[g] = img[g];
+    d1 = wave_sum_i32(d1); d2 = wave_sum_i32(d2);
+    if ((threadIdx.x & 63) == 0) {
+        if (d1) atomicAdd(&dh[1], d1);
+        if (d2) atomicAdd(&dh[2], d2);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 256; i += T) {
+        const int x = dh[i];
+        if (x) atomicAdd(&hist_rep[(uint64_t)(blockIdx.x % HIST_REPLICAS) * 256 + i], (unsigned long long)(long long)x);
+    }
 }
 
 // sums the per-bucket histogram rows into the running 256-bin histogram (signed deltas: two's complement adds)
@@ -732,6 +833,23 @@ void part_set_attributes() {
     hipFuncSetAttribute((const void *)k_bucket_count<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute((const void *)k_bucket_count_half<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute((const void *)k_bucket_count_half_lean<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute((const void *)k_bucket_count_bytes<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, K6_BYTES_LDS);
+}
+
+// tooling (tools/occupancy.py): resident workgroups per CU of the bucket-count kernels as the runtime computes them
+extern "C" int pk_internal_occupancy(int which) {
+    int n = -1;
+    hipError_t e = hipErrorInvalidValue;
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_bucket_count_half<1024>, 1024, 65536);
+    if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_bucket_count_bytes<1024>, 1024, K6_BYTES_LDS);
+    if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_bucket_count_half_lean<1024>, 1024, 65536);
+    if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_scatter2<true, 512, 32>, 512, SCATTER_LDS_NARROW);
+    return e == hipSuccess ? n : -(int)e;
+}
+
+static bool pk_bytes_enabled() {                                         // PK_K6_BYTES=0: the two-halves kernel for sparse tables (comparison runs)
+    static const bool on = !(getenv("PK_K6_BYTES") && atoi(getenv("PK_K6_BYTES")) == 0);
+    return on;
 }
 
 // Everything behind the squeeze pass for one feed: bucket layout (sampled with `stride`; 1 = exact), the fused
@@ -804,6 +922,9 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     if (pl.fb_bits == 15)                                                // 64 KiB of counters: two workgroups per CU
         hipLaunchKernelGGL(k_bucket_count_half_lean<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, k6_start, k6_end, pl.fb_bits, split, table8,
                            fresh ? 1u : 0u, bucket_hist, (const uint32_t *)flags);
+    else if (split && pk_bytes_enabled())
+        hipLaunchKernelGGL(k_bucket_count_bytes<1024>, dim3(nfb), dim3(1024), K6_BYTES_LDS, s, final_recs, k6_start, k6_end, table8, fresh ? 1u : 0u, bucket_hist,
+                           (const uint32_t *)flags);
     else if (split)
         hipLaunchKernelGGL(k_bucket_count_half<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, k6_start, k6_end, pl.fb_bits, split, table8,
                            fresh ? 1u : 0u, bucket_hist, (const uint32_t *)flags);

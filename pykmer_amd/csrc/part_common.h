@@ -12,6 +12,20 @@ constexpr int SC_T = 1024;           // threads of the scatter / bucket-count wo
 constexpr int SC_PER = 16;           // records per thread per tile
 constexpr int TILE = SC_T * SC_PER;  // 16384 records per tile = one FASTA chunk's worth (one base per byte at most)
 
+// batch sizes of the sort tile's parking / write-out phases (scatter_tile; 0 = record by record), per level
+#ifndef PK_PB_L1
+#define PK_PB_L1 0
+#endif
+#ifndef PK_SB_L1
+#define PK_SB_L1 8          // 32-bit k-mers only (the 64-bit kernel loses with it: 2.22 -> 2.29 ms)
+#endif
+#ifndef PK_PB_L2
+#define PK_PB_L2 0
+#endif
+#ifndef PK_SB_L2
+#define PK_SB_L2 8
+#endif
+
 // ------------------------------------------------------------------ hot keys ---------------------
 // Tandem repeats (poly-A/T, (AT)n, (AAG)n ...) put tens of millions of identical canonical k-mers on a
 // handful of addresses; routed like everything else they would all land in ONE final bucket, i.e. on
@@ -128,7 +142,7 @@ constexpr size_t SCATTER_LDS_WIDE = sizeof(ScatterLds);            // 104 KiB
 // (off[d] ends at the start of run d + 1; gbase keeps the starts).  Round 1 ranked with one returning add and kept
 // digit and rank of every record in a register until the scan was done: 16 or 32 more live registers and three to
 // four more vector instructions per record, in kernels that are bound by instruction issue.
-template <typename RIN, bool WIDE, int NT = SC_T, int PER = SC_PER, int NB = 512, bool FULL = false, class Settle>
+template <typename RIN, bool WIDE, int NT = SC_T, int PER = SC_PER, int NB = 512, bool FULL = false, int PB = 0, int SB = 0, class Settle>
 __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[PER], uint32_t okm, uint32_t n_tile,
                                              uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out,
                                              Settle &&settle, uint32_t *claim = nullptr, const uint32_t *__restrict__ cap_end = nullptr,
@@ -153,13 +167,18 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
 #pragma unroll
         for (int j = 0; j < PER; j++)
             __hip_atomic_fetch_add(&L.hist[KEEP_DG ? dg[KEEP_DG ? j : 0] : slot_digit(j)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!FULL && threadIdx.x < 64u) L.off[NB + threadIdx.x] = (uint32_t)TILE + threadIdx.x;   // where empty slots park (adds of zero)
     } else {
         // 32 records per thread: every record under its own test (32 digits in registers spill)
 #pragma unroll
-        for (int j = 0; j < PER; j++)
+        for (int j = 0; j < PER; j++) {
+#ifdef PK_CNT_BF
+            __hip_atomic_fetch_add(&L.hist[slot_digit(j)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
             if (FULL || ((okm >> j) & 1u)) __hip_atomic_fetch_add(&L.hist[digit_of(r[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+        }
     }
+    if (!FULL && threadIdx.x < 64u) L.off[NB + threadIdx.x] = (uint32_t)TILE + threadIdx.x;   // where empty slots park (adds of zero)
     __syncthreads();
     // exclusive scan of hist[0..B) by the first B threads (B <= NB <= NT)
     uint32_t my_off = 0, claimed = 0;
@@ -190,55 +209,97 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     }
     __syncthreads();
     if (n_tile == ~0u) n_tile = L.total;
-    if (PER <= 16) {
+    // Parking.  PB == 0: record by record (returning add, then the write it places); every add is waited for on the spot
+    // -- the compiler may not move an LDS write across the next atomic -- so a thread walks a chain of PER LDS round
+    // trips, which the other waves of the CU cover.  PB > 0: PB returning adds back to back, then their PB writes.
+    if constexpr (PB == 0) {
+        if (PER <= 16) {
 #pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const uint32_t d = KEEP_DG ? dg[KEEP_DG ? j : 0] : slot_digit(j);
-            const uint32_t p = atomicAdd(&L.off[d], (FULL || ((okm >> j) & 1u)) ? 1u : 0u);
-            if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)d; }
-            else L.rec[p] = (uint32_t)r[j];
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < PER; j++)
-            if (FULL || ((okm >> j) & 1u)) {
-                const uint32_t d = digit_of(r[j]);
-                const uint32_t p = atomicAdd(&L.off[d], 1u);
+            for (int j = 0; j < PER; j++) {
+                const uint32_t d = KEEP_DG ? dg[KEEP_DG ? j : 0] : slot_digit(j);
+                const uint32_t p = atomicAdd(&L.off[d], (FULL || ((okm >> j) & 1u)) ? 1u : 0u);
                 if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)d; }
                 else L.rec[p] = (uint32_t)r[j];
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; j++)
+                if (FULL || ((okm >> j) & 1u)) {
+                    const uint32_t d = digit_of(r[j]);
+                    const uint32_t p = atomicAdd(&L.off[d], 1u);
+                    if (WIDE) { L.rec[p] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p] = (uint16_t)d; }
+                    else L.rec[p] = (uint32_t)r[j];
+                }
+        }
+    } else {
+        static_assert(PB == 0 || PER % (PB ? PB : 1) == 0, "parking batch");
+#pragma unroll
+        for (int j0 = 0; j0 < PER; j0 += (PB ? PB : 1)) {
+            uint32_t p[PB ? PB : 1], d[PB ? PB : 1];
+#pragma unroll
+            for (int u = 0; u < PB; u++) {
+                const int j = j0 + u;
+                const bool ok = FULL || ((okm >> j) & 1u);
+                d[u] = KEEP_DG ? dg[KEEP_DG ? j : 0] : (ok ? digit_of(r[j]) : (uint32_t)NB + lane);
+                p[u] = atomicAdd(&L.off[d[u]], ok ? 1u : 0u);         // empty slots: add zero on the lane's scratch digit, park behind the tile
+            }
+#pragma unroll
+            for (int u = 0; u < PB; u++) {
+                const int j = j0 + u;
+                if (WIDE) { L.rec[p[u]] = (uint32_t)((uint64_t)r[j] & low_mask); L.dig[p[u]] = (uint16_t)d[u]; }
+                else L.rec[p[u]] = (uint32_t)r[j];
+            }
+        }
     }
     if (claim && threadIdx.x < B) L.gbase[threadIdx.x] = claimed - my_off;   // sorted position p of digit d goes to p + gbase[d]
     __syncthreads();
     settle();
-    if (out16) {
-        // 16-bit records, one per lane and store (64 consecutive sorted positions = 128 contiguous bytes of a run, or of two)
-        uint16_t *o16 = reinterpret_cast<uint16_t *>(out);
+    // Run write-out, one record per lane and store: 64 consecutive sorted positions are 64 consecutive records of a run
+    // (or of two).  32-bit records keep what they had above `low_mask` (narrow: the digit; wide: nothing) -- every
+    // reader of 32-bit records masks for itself.  (Storing neighbours pairwise as 8 bytes, as round 1 did, halves the
+    // store instructions but costs 15 vector instructions per record against 5 here.)
+    // SB == 0: position by position (parked record, its digit's run base, store: two LDS round trips each).  SB > 0: SB
+    // positions at a time -- the reads are unconditional then: positions past n_tile hold stale records whose digit
+    // field still indexes gbase in range; only the stores are masked.
+    auto store_runs = [&](auto *o) {
+        constexpr bool O16 = sizeof(*o) == 2;
+        if constexpr (SB == 0) {
 #pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const uint32_t p = threadIdx.x + (uint32_t)j * NT;
-            if (p < n_tile) {
-                const uint32_t r0 = L.rec[p];
-                const uint32_t d0 = WIDE ? (uint32_t)L.dig[p] : __builtin_amdgcn_ubfe(r0, shift, dbits);
-                o16[p + L.gbase[d0]] = (uint16_t)(r0 & low_mask);
+            for (int j = 0; j < PER; j++) {
+                const uint32_t p = threadIdx.x + (uint32_t)j * NT;
+                if (p < n_tile) {
+                    const uint32_t r0 = L.rec[p];
+                    const uint32_t d0 = WIDE ? (uint32_t)L.dig[p] : __builtin_amdgcn_ubfe(r0, shift, dbits);
+                    if (O16) o[p + L.gbase[d0]] = (uint16_t)(r0 & low_mask);
+                    else o[p + L.gbase[d0]] = r0;
+                }
+            }
+        } else {
+            static_assert(SB == 0 || PER % (SB ? SB : 1) == 0, "store batch");
+#pragma unroll
+            for (int j0 = 0; j0 < PER; j0 += (SB ? SB : 1)) {
+                uint32_t r0[SB ? SB : 1], g0[SB ? SB : 1];
+#pragma unroll
+                for (int u = 0; u < SB; u++) r0[u] = L.rec[threadIdx.x + (uint32_t)(j0 + u) * NT];
+#pragma unroll
+                for (int u = 0; u < SB; u++) {
+                    const uint32_t p = threadIdx.x + (uint32_t)(j0 + u) * NT;
+                    const uint32_t d0 = WIDE ? ((uint32_t)L.dig[p] & (uint32_t)(NB - 1)) : __builtin_amdgcn_ubfe(r0[u], shift, dbits);
+                    g0[u] = L.gbase[d0];
+                }
+#pragma unroll
+                for (int u = 0; u < SB; u++) {
+                    const uint32_t p = threadIdx.x + (uint32_t)(j0 + u) * NT;
+                    if (FULL || p < n_tile) {
+                        if (O16) o[p + g0[u]] = (uint16_t)(r0[u] & low_mask);
+                        else o[p + g0[u]] = r0[u];
+                    }
+                }
             }
         }
-    } else {
-        // 32-bit records, one per lane and store: 64 consecutive sorted positions are 64 consecutive dwords of a run (or of
-        // two).  The parked record still carries what it had above `low_mask` (narrow: its digit; wide: nothing) -- every
-        // reader of 32-bit records masks for itself.  (Storing neighbours pairwise as 8 bytes, as round 1 did, halves the
-        // store instructions but costs 15 vector instructions per record against 5 here, and the kernel is issue-bound.)
-        uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
-#pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const uint32_t p = threadIdx.x + (uint32_t)j * NT;
-            if (p < n_tile) {
-                const uint32_t r0 = L.rec[p];
-                const uint32_t d0 = WIDE ? (uint32_t)L.dig[p] : __builtin_amdgcn_ubfe(r0, shift, dbits);
-                o32[p + L.gbase[d0]] = r0;
-            }
-        }
-    }
+    };
+    if (out16) store_runs(reinterpret_cast<uint16_t *>(out));
+    else store_runs(reinterpret_cast<uint32_t *>(out));
     __syncthreads();
 }
 

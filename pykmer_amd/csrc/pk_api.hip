@@ -212,6 +212,7 @@ struct pk_indexer {
     hipEvent_t ev[12] = {};
     double t_scan = 0, t_squeeze = 0, t_sort = 0, t_final = 0, t_zero = 0, t_part = 0, t_bucket = 0;
     int feeds = 0, relayouts = 0;
+    uint64_t recounted = 0;                                // buckets whose byte counters wrapped and were counted again (k_bucket_count_bytes)
     bool table_fresh = true;         // no feed has written the u8 table since the last reset
     uint8_t *ws = nullptr;           // workspace of the partition passes
     size_t ws_cap = 0;
@@ -238,7 +239,7 @@ static int ix_reset(pk_indexer *ix) {
     ix->finished = false;
     ix->table_fresh = true;
     ix->t_scan = ix->t_squeeze = ix->t_sort = ix->t_final = ix->t_part = ix->t_bucket = 0;
-    ix->feeds = ix->relayouts = 0;
+    ix->feeds = ix->relayouts = 0; ix->recounted = 0;
     return PK_OK;
 }
 
@@ -368,7 +369,7 @@ static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
         HIPCHK(hipMemcpyAsync(flags, ix->ws + lay.side_n + 8, sizeof flags, hipMemcpyDeviceToHost, ix->stream));
         HIPCHK(hipStreamSynchronize(ix->stream));
         HIPCHK(hipGetLastError());
-        if (!flags[0]) break;
+        if (!flags[0]) { ix->recounted += flags[1]; break; }
         if (stride == 1) return fail(PK_ERR_HIP, "level-1 buckets overflowed an exact layout (internal error)");
         ix->relayouts++;
     }
@@ -522,7 +523,7 @@ extern "C" int pk_indexer_timings(pk_indexer *ix, double out[10]) {
     if (!ix || !out) return fail(PK_ERR_ARG, "null argument");
     for (int i = 0; i < 10; i++) out[i] = 0;
     out[0] = ix->t_scan; out[1] = ix->t_squeeze; out[2] = ix->t_final; out[3] = ix->t_zero; out[4] = (double)ix->feeds;
-    out[5] = ix->t_part; out[6] = ix->t_bucket; out[7] = ix->t_sort; out[8] = (double)ix->relayouts;
+    out[5] = ix->t_part; out[6] = ix->t_bucket; out[7] = ix->t_sort; out[8] = (double)ix->relayouts; out[9] = (double)ix->recounted;
     return PK_OK;
 }
 
