@@ -194,6 +194,9 @@ struct pk_indexer {
     hipStream_t stream = nullptr;
     uint8_t *table8 = nullptr;       // the .kin image
     Carry *carry = nullptr;
+    Carry *carry0 = nullptr;           // the parser state of an empty stream (device copy: a reset is a device-to-device copy, no host wait)
+    struct Pinned { Carry carry; unsigned long long hist[256]; uint64_t n_recs; uint32_t flags[2]; } *pin = nullptr;   // pinned landing zone of the small read-backs
+    bool zero_timed = true;            // t_zero of the last reset has been read from its events
     unsigned long long *hist = nullptr;
     DevRec *recs = nullptr;
     uint64_t recs_cap = 0;
@@ -222,19 +225,14 @@ static int ix_reset(pk_indexer *ix) {
     HIPCHK(hipSetDevice(ix->device));
     HIPCHK(hipEventRecord(ix->ev[6], ix->stream));
     // the first feed writes every slice of the u8 table itself (k_bucket_count, fresh); the table is only
-    // zeroed if nothing gets fed at all (see pk_indexer_finish)
-    HIPCHK(hipEventRecord(ix->ev[7], ix->stream));
-    Carry c;
-    memset(&c, 0, sizeof c);
-    c.l1 = 8u | 1u | (LS_START << 1);                    // l1_state(LS_START)
-    c.l2.flags = F_NONID | F_PRESET | F_BRK;             // l2_state(0, 0, 0, 0)
-    HIPCHK(hipMemcpyAsync(ix->carry, &c, sizeof c, hipMemcpyHostToDevice, ix->stream));
+    // zeroed if nothing gets fed at all (see pk_indexer_finish).  Nothing here waits for the device: the stream orders
+    // the reset behind whatever is still running, and its duration is read at the next point that waits anyway.
+    HIPCHK(hipMemcpyAsync(ix->carry, ix->carry0, sizeof(Carry), hipMemcpyDeviceToDevice, ix->stream));
     HIPCHK(hipMemsetAsync(ix->hist, 0, 256 * sizeof(unsigned long long), ix->stream));
     if (ix->recs) HIPCHK(hipMemsetAsync(ix->recs, 0, ix->recs_cap * sizeof(DevRec), ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, ix->ev[6], ix->ev[7]));
-    ix->t_zero = ms * 1e-3;
+    HIPCHK(hipEventRecord(ix->ev[7], ix->stream));
+    ix->zero_timed = false;
+    ix->t_zero = 0;
     ix->bytes_fed = ix->n_recs = 0;
     ix->finished = false;
     ix->table_fresh = true;
@@ -243,11 +241,20 @@ static int ix_reset(pk_indexer *ix) {
     return PK_OK;
 }
 
+// after a wait on the stream: the duration of the last reset, if it has not been read yet
+static void time_reset(pk_indexer *ix) {
+    if (ix->zero_timed) return;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ix->ev[6], ix->ev[7]) == hipSuccess) ix->t_zero = ms * 1e-3;
+    ix->zero_timed = true;
+}
+
 extern "C" void pk_indexer_destroy(pk_indexer *ix) {
     if (!ix) return;
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
-    hipFree(ix->table8); hipFree(ix->carry); hipFree(ix->hist); hipFree(ix->recs);
+    hipFree(ix->table8); hipFree(ix->carry); hipFree(ix->carry0); hipFree(ix->hist); hipFree(ix->recs);
+    if (ix->pin) hipHostFree(ix->pin);
     hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state); hipFree(ix->packs); hipFree(ix->chunk_odd); hipFree(ix->t_l1); hipFree(ix->t_l2); hipFree(ix->staging[0]); hipFree(ix->staging[1]); hipFree(ix->ws);
     for (auto &e : ix->ev) if (e) hipEventDestroy(e);
     if (ix->stream) hipStreamDestroy(ix->stream);
@@ -280,6 +287,15 @@ extern "C" int pk_indexer_create_slice(pk_indexer **out, int k, int device, int 
     for (auto &ev : ix->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc(&ix->table8, std::max<uint64_t>(ix->n, 16))) != hipSuccess) return bail(e, "hipMalloc(u8 table)");
     if ((e = hipMalloc(&ix->carry, sizeof(Carry))) != hipSuccess) return bail(e, "hipMalloc(carry)");
+    if ((e = hipMalloc(&ix->carry0, sizeof(Carry))) != hipSuccess) return bail(e, "hipMalloc(carry0)");
+    if ((e = hipHostMalloc(&ix->pin, sizeof(*ix->pin), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+    {
+        Carry c;
+        memset(&c, 0, sizeof c);
+        c.l1 = 8u | 1u | (LS_START << 1);                    // l1_state(LS_START)
+        c.l2.flags = F_NONID | F_PRESET | F_BRK;             // l2_state(0, 0, 0, 0)
+        if ((e = hipMemcpy(ix->carry0, &c, sizeof c, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(carry0)");
+    }
     if ((e = hipMalloc(&ix->hist, 256 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(hist)");
     part_set_attributes();                               // dynamic-LDS opt-ins, once per process and device
     rc = ix_reset(ix);
@@ -339,9 +355,10 @@ static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
     launch_chunk_l2(f, n_bytes, ix->c_l1s, ix->c_l2, ix->lane_state, ix->packs, ix->chunk_odd, n_chunks, (uint32_t)ix->k, ix->stream);
     launch_scan_l2(ix->c_l2, n_chunks, ix->carry, ix->c_l2s, ix->t_l2, (uint32_t)ix->k, ix->stream);
     HIPCHK(hipEventRecord(ix->ev[1], ix->stream));
-    uint64_t n_recs = 0;
-    HIPCHK(hipMemcpyAsync(&n_recs, &ix->carry->n_recs, sizeof n_recs, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipMemcpyAsync(&ix->pin->n_recs, &ix->carry->n_recs, sizeof(uint64_t), hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
+    time_reset(ix);
+    const uint64_t n_recs = ix->pin->n_recs;
     rc = ensure_recs(ix, n_recs);
     if (rc) return rc;
     ix->n_recs = n_recs;
@@ -365,8 +382,8 @@ static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
                                ix->table_fresh, ix->hist))
             return fail(PK_ERR_HIP, "partition pipeline launch failed: %s", hipGetErrorString(hipGetLastError()));
         HIPCHK(hipEventRecord(ix->ev[9], ix->stream));
-        uint32_t flags[2] = {0, 0};
-        HIPCHK(hipMemcpyAsync(flags, ix->ws + lay.side_n + 8, sizeof flags, hipMemcpyDeviceToHost, ix->stream));
+        volatile uint32_t *flags = ix->pin->flags;
+        HIPCHK(hipMemcpyAsync(ix->pin->flags, ix->ws + lay.side_n + 8, sizeof ix->pin->flags, hipMemcpyDeviceToHost, ix->stream));
         HIPCHK(hipStreamSynchronize(ix->stream));
         HIPCHK(hipGetLastError());
         if (!flags[0]) { ix->recounted += flags[1]; break; }
@@ -452,20 +469,22 @@ extern "C" int pk_indexer_finish(pk_indexer *ix, uint64_t *num_kmers_out, uint64
         // the value histogram was kept up to date by k_bucket_count / k_apply_side: no pass over the table
         HIPCHK(hipEventRecord(ix->ev[5], ix->stream));
         HIPCHK(hipGetLastError());
+        // the totals and the histogram land in pinned memory behind the last kernel: one wait for everything
+        HIPCHK(hipMemcpyAsync(&ix->pin->carry, ix->carry, sizeof(Carry), hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipMemcpyAsync(ix->pin->hist, ix->hist, sizeof ix->pin->hist, hipMemcpyDeviceToHost, ix->stream));
         HIPCHK(hipStreamSynchronize(ix->stream));
+        time_reset(ix);
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, ix->ev[4], ix->ev[5]));
         ix->t_final = ms * 1e-3;
         ix->finished = true;
     }
-    Carry c;
-    HIPCHK(hipMemcpy(&c, ix->carry, sizeof c, hipMemcpyDeviceToHost));
+    const Carry &c = ix->pin->carry;
     if (num_kmers_out) *num_kmers_out = c.num_kmers;
     if (total_bp_out) *total_bp_out = c.total_bp;
     if (n_recs_out) *n_recs_out = c.n_recs;
     if (hist256_out) {
-        unsigned long long h[256];
-        HIPCHK(hipMemcpy(h, ix->hist, sizeof h, hipMemcpyDeviceToHost));
+        const unsigned long long *h = ix->pin->hist;
         uint64_t nonzero = 0;
         for (int v = 1; v < 256; v++) { hist256_out[v] = h[v]; nonzero += h[v]; }
         hist256_out[0] = ix->n - nonzero;                // zeros are not tallied on the device

@@ -377,3 +377,46 @@ def test_bucket_overflow_takes_the_exact_relayout(gpu, k, unit_len):
         assert np.array_equal(table[u.astype(np.int64)], sat)
         step = 1 << 30
         assert sum(int(np.count_nonzero(table[o:o + step])) for o in range(0, table.size, step)) == u.size
+
+
+def _interspersed_repeat(n_copies, unit_len, spacer, seed):
+    """`n_copies` of one unit, each followed by `spacer` random bases: every k-mer of the unit occurs n_copies times, but
+    never with a period of 1-3 bases (the hot-key path does not see it) and never as a long run of records in one bucket."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    unit = acgt[rng.integers(0, 4, size=unit_len)]
+    parts = []
+    for _ in range(n_copies):
+        parts.append(unit)
+        parts.append(acgt[rng.integers(0, 4, size=spacer)])
+    seq = np.concatenate(parts)
+    seq = seq[: seq.size // 60 * 60]
+    lines = np.empty((seq.size // 60, 61), dtype=np.uint8)
+    lines[:, :60] = seq.reshape(-1, 60)
+    lines[:, 60] = 10
+    return b">interspersed\n" + lines.tobytes()
+
+
+@pytest.mark.parametrize("k", [9, 17])
+def test_byte_counters_wrap_and_are_recounted(gpu, k):
+    """Sparse tables count in byte counters (k_bucket_count_bytes).  A k-mer that occurs more than 254 times in a bucket
+    visit wraps its byte; the add that sees 255 raises the flag and the bucket is counted again with 16-bit counters
+    (`buckets_recounted`).  Second feed of the same text: the bytes come back from HBM already at 255."""
+    copies = 300 if k == 9 else 400
+    data = _interspersed_repeat(copies, 70, 20 if k == 9 else 5000, seed=k)
+    assert k != 9 or len(data) < 4 * 8192                                  # k = 9: four final buckets, still "sparse"
+    kmers = oracle.kmer_list(data, k)
+    u, c = np.unique(kmers, return_counts=True)
+    assert (c >= copies).sum() >= 70 - k + 1
+    with gpu.Indexer(k) as ix:
+        for feed in (1, 2):
+            ix.feed(data)
+            assert ix.timings()["buckets_recounted"] >= feed
+        fin = ix.finish()
+        sat = np.minimum(2 * c, 255).astype(np.uint8)
+        assert fin["num_kmers"] == 2 * kmers.size
+        assert np.array_equal(fin["hist256"][1:], np.bincount(sat, minlength=256)[1:].astype(np.uint64))
+        table = ix.table_to_host()
+        assert np.array_equal(table[u.astype(np.int64)], sat)
+        step = 1 << 30
+        assert sum(int(np.count_nonzero(table[o:o + step])) for o in range(0, table.size, step)) == u.size
