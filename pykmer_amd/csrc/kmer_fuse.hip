@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
     const uint32_t t = threadIdx.x;
     __syncthreads();
     // items: this workgroup's slots (persistent over a contiguous range), or every stride-th slot when sampling
-    const uint32_t i_lo = COUNT ? blockIdx.x : blockIdx.x * pl.G, i_hi = COUNT ? n_items : min(i_lo + pl.G, n_items);
+    const uint32_t i_lo = COUNT ? blockIdx.x : blockIdx.x * pl.G1, i_hi = COUNT ? n_items : min(i_lo + pl.G1, n_items);
     const uint32_t i_step = COUNT ? gridDim.x : 1u;
     // One slot's worth of input per thread: the base count, the thread's NW code dwords and the one before them, the two
     // restart dwords, the chunk's start state.  All of it is requested one tile AHEAD (before the current tile is
@@ -351,9 +351,14 @@ __device__ __forceinline__ uint32_t room_for(unsigned long long h, double scale,
 }
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if (lane >= d) v += o; }
+    // DPP: shifts inside the rows of 16 lanes, then the row totals broadcast into the rows behind them (no LDS traffic;
+    // the shuffle form went through ds_bpermute six times per scan, 64 scans per wave in k_provision)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2, 3
     return v;
 }
 
@@ -389,7 +394,11 @@ __global__ __launch_bounds__(1024) void k_provision(const uint32_t *__restrict__
         if ((uint32_t)r < rows) {                           // uniform
             const uint32_t i = w * seg + (uint32_t)r * 64u + lane;
             const bool in = i < n_tally;
-            if (in && h[r]) atomicAdd(&sum1[two ? (i >> pl.b2) : i], (unsigned long long)h[r]);
+            if (two && pl.b2 >= 6u) {
+                // a row of 64 final buckets lies inside one level-1 bucket: one add per row, not 64 on one LDS address
+                const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(in ? h[r] : 0u), 63);
+                if (lane == 0 && row) atomicAdd(&sum1[i >> pl.b2], (unsigned long long)row);
+            } else if (in && h[r]) atomicAdd(&sum1[two ? (i >> pl.b2) : i], (unsigned long long)h[r]);
             if (two) {
                 const uint32_t mine = in ? ((room_for(h[r], scale, stride, 2048u) + 7u) & ~7u) : 0u;   // 16-bit records: starts stay 16-byte aligned
                 const uint32_t inc = wave_incl_scan_u32(mine);
@@ -528,7 +537,7 @@ void launch_walk_sort(const uint32_t *codes, const uint32_t *restarts, const uin
                       uint32_t *compact_base, uint32_t *wg2_start, unsigned long long *side, unsigned long long *side_n, uint64_t side_cap,
                       hipStream_t s) {
     const uint32_t dump = (uint32_t)pl.capacity1;
-    launch_ws<false>(pl, pl.n_wg0, pl.k > 15 ? SCATTER_LDS_WIDE : FUSE_LDS_NARROW, s, codes, restarts, n_bases, st2, pl, pl.n_chunks, 1u, out1, cursor1,
+    launch_ws<false>(pl, pl.n_wg1, pl.k > 15 ? SCATTER_LDS_WIDE : FUSE_LDS_NARROW, s, codes, restarts, n_bases, st2, pl, pl.n_chunks, 1u, out1, cursor1,
                      cap_end, dump, flags, 0u, 0u, (uint32_t *)nullptr, side, side_n, side_cap);
     hipLaunchKernelGGL(k_level1_finish, dim3(1), dim3(1024), 0, s, (const uint32_t *)cursor1, bucket_base, cap_end, pl, bucket_end, compact_base,
                        wg2_start, (const uint32_t *)flags);

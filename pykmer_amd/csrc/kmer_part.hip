@@ -96,9 +96,8 @@ __global__ __launch_bounds__(512) void k_rows2_scan(const uint32_t *__restrict__
 }
 
 // ---- sample2: final-bucket sizes from a sample of the level-1 records (2^15 < final buckets <= 2^18: k = 17, slices of k = 19).
-// One workgroup per level-1 bucket tallies the level-2 digit of every stride2-th block of 1024 records in LDS (stride2 = 1:
-// all of them, i.e. exact).  Blocks are what tiles of the level-1 sort wrote, so this samples stretches of the text like the
-// slot sample of level 1 does.  It replaces the exact counting pass over ALL level-1 records (k_count2: 0.66 ms at k = 17).
+// One workgroup per level-1 bucket tallies the level-2 digit of every stride2-th group of 64 records in LDS (stride2 = 1:
+// all of them, i.e. exact).  It replaces the exact counting pass over ALL level-1 records (k_count2: 0.66 ms at k = 17).
 __global__ __launch_bounds__(1024) void k_sample2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ bucket_base,
                                                   const uint32_t *__restrict__ bucket_end, PartPlan pl, uint32_t stride2,
                                                   uint32_t *__restrict__ tally, uint32_t *__restrict__ sampled_n,
@@ -110,16 +109,22 @@ __global__ __launch_bounds__(1024) void k_sample2(const uint32_t *__restrict__ i
     if (threadIdx.x < 512) h[threadIdx.x] = 0;
     if (threadIdx.x == 0) n_seen = 0;
     __syncthreads();
-    const uint32_t n_blk = (hi - lo + 1023u) / 1024u, mask = pl.B2 - 1u, shift = pl.fb_bits;
+    // The sample is every stride2-th GROUP of 64 records (one wave load).  Records of one stretch of text lie together in
+    // a level-1 bucket, and a repeat family can put tens of thousands of records of ONE final bucket into such a
+    // stretch: sampled in blocks of 1024 records (as at first) a stretch of 87 K records is 5 or 6 blocks -- an estimate
+    // 19 % off, beyond the 12.5 % + 4096 of slack, and which blocks are hit depends on the order the tiles claimed
+    // their runs in, i.e. on timing (seen as an occasional re-layout at k = 17 when the level-1 grid changed).
+    const uint32_t n_grp = (hi - lo + 63u) / 64u, n_sgrp = (n_grp + stride2 - 1u) / stride2;
+    const uint32_t mask = pl.B2 - 1u, shift = pl.fb_bits, w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t mine = 0;
-    for (uint32_t blk0 = 0; blk0 < n_blk; blk0 += 8u * stride2) {        // eight loads in flight per lane
+    for (uint32_t s0 = 0; s0 < n_sgrp; s0 += 8u * 16u) {                 // sixteen waves, eight loads in flight per lane
         uint32_t v[8];
         bool ok[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const uint32_t blk = blk0 + (uint32_t)u * stride2;
-            const uint64_t i = (uint64_t)lo + (uint64_t)blk * 1024u + threadIdx.x;
-            ok[u] = blk < n_blk && i < hi;
+            const uint32_t sg = s0 + (uint32_t)u * 16u + w;
+            const uint64_t i = (uint64_t)lo + (uint64_t)sg * stride2 * 64u + lane;
+            ok[u] = sg < n_sgrp && i < hi;
             v[u] = ok[u] ? in[i] : 0u;
         }
 #pragma unroll
@@ -328,7 +333,9 @@ __device__ __forceinline__ uint32_t pack_low_bytes(uint32_t x0, uint32_t x1) {  
 struct SliceTally {
     int d1 = 0, d2 = 0;
     // Four table bytes: how many equal 1, how many equal 2 (two bit planes and a population count each); whatever is 3 or
-    // more goes to the LDS bins one byte at a time.  Bytes above 3 are first taken out of the planes.
+    // more goes to the LDS bins one byte at a time.  Bytes above 3 are first taken out of the planes.  (A third plane -- the
+    // values 1 .. 7 by seven population counts, only bytes >= 8 through the bins -- was measured on the dense k = 15 table,
+    // where 81 M addresses hold 3 or more: 0.76 -> 0.87 ms; five more live tallies in a kernel capped at 64 registers.)
     __device__ __forceinline__ void add_dword(int *dh, uint32_t x, int sign) {
         uint32_t p0 = x & 0x01010101u, p1 = (x >> 1) & 0x01010101u;
         uint32_t rest = p0 & p1;                                         // bytes equal to 3 (if nothing above)
@@ -776,6 +783,12 @@ PartPlan make_part_plan(uint32_t k, uint64_t n_bytes, uint32_t slice_bits, uint3
     if (pl.n_wg0 == 0) pl.n_wg0 = 1;
     pl.G = (pl.n_chunks + pl.n_wg0 - 1) / pl.n_wg0;
     if (pl.G == 0) pl.G = 1;
+    static const uint32_t wg1_env = getenv("PK_WG1") ? (uint32_t)atoi(getenv("PK_WG1")) : 0u;
+    const uint32_t wg1 = wg1_env ? wg1_env : 4096u;       // shorter stretches per workgroup even out the last round (1024: 1.42 ms, 4096: 1.39)
+    pl.n_wg1 = pl.n_chunks < wg1 ? pl.n_chunks : wg1;
+    if (pl.n_wg1 == 0) pl.n_wg1 = 1;
+    pl.G1 = (pl.n_chunks + pl.n_wg1 - 1) / pl.n_wg1;
+    if (pl.G1 == 0) pl.G1 = 1;
     uint64_t r2 = (n_bytes + 1023) / 1024;
     pl.R2 = r2 < (uint64_t)TILE ? (uint64_t)TILE : ((r2 + TILE - 1) / TILE) * TILE;
     pl.n_wg2_max = (uint32_t)(n_bytes / pl.R2) + pl.B1 + 1;

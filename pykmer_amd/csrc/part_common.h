@@ -29,13 +29,11 @@ constexpr int TILE = SC_T * SC_PER;  // 16384 records per tile = one FASTA chunk
 // ------------------------------------------------------------------ hot keys ---------------------
 // Tandem repeats (poly-A/T, (AT)n, (AAG)n ...) put tens of millions of identical canonical k-mers on a
 // handful of addresses; routed like everything else they would all land in ONE final bucket, i.e. on
-// one CU.  Each lane therefore remembers its last three distinct k-mers (periods 1-3 cover poly-N,
-// dinucleotide and trinucleotide repeats): a k-mer is emitted the first time it is seen, repeats while
-// it is remembered only bump a lane counter, and evicted counters are tallied in a per-workgroup LDS
-// hash table (addr -> count; lanes holding the same address are merged with ballot + readlane first),
-// which is appended to a global side list when the workgroup finishes (or the table half fills).
-// k_apply_side folds the side list into the finished u8 table with saturating CAS adds -- a few
-// thousand entries instead of 10^7..10^8 records.
+// one CU.  The level-1 kernel (kmer_fuse.hip) finds k-mers that repeat the one 1, 2 or 3 bases earlier from the
+// packed bases themselves, keeps them out of the record stream and tallies them in this per-workgroup LDS
+// hash table (addr -> count), which is appended to a global side list when the workgroup finishes (or the
+// table half fills).  k_apply_side folds the side list into the finished u8 table with saturating CAS
+// adds -- a few thousand entries instead of 10^7..10^8 records.
 constexpr uint32_t HOT_PROBES = 16;
 constexpr uint32_t SIDE_CNT_BITS = 28;   // side entry = (addr << 28) | count
 
@@ -155,10 +153,13 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     };
     // PER <= 16: the digit, or this lane's scratch digit for an empty slot.  64-bit records do not keep it (the k = 17
     // kernel is out of registers as it is: 28 were spilled to scratch memory) and cut it from the record again when parking.
+    // <= 16 records per thread: empty slots take a scratch digit instead of a branch (measured the other way round for the
+    // 64-bit kernel too: per-record tests cost it 2.22 -> 2.36 ms)
+    constexpr bool BRANCH_FREE = PER <= 16;
     constexpr bool KEEP_DG = PER <= 16 && sizeof(RIN) == 4;
     uint32_t dg[KEEP_DG ? PER : 1];
     auto slot_digit = [&](int j) -> uint32_t { return (FULL || ((okm >> j) & 1u)) ? digit_of(r[j]) : (uint32_t)NB + lane; };
-    if (PER <= 16) {
+    if (BRANCH_FREE) {
         // branch-free: an LDS operation behind a branch is waited for on the spot, sixteen back to back cost one round trip
         if (KEEP_DG) {
 #pragma unroll
@@ -168,14 +169,11 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
         for (int j = 0; j < PER; j++)
             __hip_atomic_fetch_add(&L.hist[KEEP_DG ? dg[KEEP_DG ? j : 0] : slot_digit(j)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
-        // 32 records per thread: every record under its own test (32 digits in registers spill)
+        // 32 records per thread: every record under its own test (32 digits in registers spill; scratch digits instead of
+        // the tests: 1.42 -> 1.60 ms)
 #pragma unroll
         for (int j = 0; j < PER; j++) {
-#ifdef PK_CNT_BF
-            __hip_atomic_fetch_add(&L.hist[slot_digit(j)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
             if (FULL || ((okm >> j) & 1u)) __hip_atomic_fetch_add(&L.hist[digit_of(r[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
         }
     }
     if (!FULL && threadIdx.x < 64u) L.off[NB + threadIdx.x] = (uint32_t)TILE + threadIdx.x;   // where empty slots park (adds of zero)
@@ -211,9 +209,10 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     if (n_tile == ~0u) n_tile = L.total;
     // Parking.  PB == 0: record by record (returning add, then the write it places); every add is waited for on the spot
     // -- the compiler may not move an LDS write across the next atomic -- so a thread walks a chain of PER LDS round
-    // trips, which the other waves of the CU cover.  PB > 0: PB returning adds back to back, then their PB writes.
+    // trips, which the other waves of the CU cover.  PB > 0: PB returning adds back to back, then their PB writes --
+    // measured and not used: level 1 1.47 -> 1.68 ms (PB = 8), 1.65 (PB = 4); level 2 unchanged.
     if constexpr (PB == 0) {
-        if (PER <= 16) {
+        if (BRANCH_FREE) {
 #pragma unroll
             for (int j = 0; j < PER; j++) {
                 const uint32_t d = KEEP_DG ? dg[KEEP_DG ? j : 0] : slot_digit(j);
@@ -260,7 +259,8 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     // store instructions but costs 15 vector instructions per record against 5 here.)
     // SB == 0: position by position (parked record, its digit's run base, store: two LDS round trips each).  SB > 0: SB
     // positions at a time -- the reads are unconditional then: positions past n_tile hold stale records whose digit
-    // field still indexes gbase in range; only the stores are masked.
+    // field still indexes gbase in range; only the stores are masked.  SB = 8: level 1 (32-bit k-mers) 1.47 -> 1.42 ms, level 2
+    // 1.27 -> 1.24; 4 about the same, 16 loses (1.58 / 1.54), and so does any batching for 64-bit k-mers.
     auto store_runs = [&](auto *o) {
         constexpr bool O16 = sizeof(*o) == 2;
         if constexpr (SB == 0) {

@@ -46,7 +46,8 @@ struct PartPlan {
     uint32_t fb_bits;        // address bits inside a final bucket (<= 16)
     uint32_t b1, b2, B1, B2; // level-1 / level-2 digit widths and bucket counts
     uint32_t n_chunks;       // 16 KiB FASTA chunks in this feed
-    uint32_t n_wg0, G;       // persistent workgroups of the squeeze / sort kernels and chunks per workgroup
+    uint32_t n_wg0, G;       // persistent workgroups of the squeeze kernel and chunks per workgroup
+    uint32_t n_wg1, G1;      // the same for the level-1 sort (k_walk_sort)
     uint64_t R2;             // records per level-2 workgroup
     uint32_t n_wg2_max;      // upper bound on level-2 workgroups
     uint32_t sample_stride;  // every how-manieth slot is tallied to size the buckets (1 = all: exact)
