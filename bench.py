@@ -223,14 +223,15 @@ def main():
     # measured HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from inside the
     # process): tools/hbm_traffic.py turns the two CSVs into profiles/hbm_traffic.json, collected on exactly this workload
     traffic = pipeline_traffic = traffic_source = None
-    tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tp) and k == 15 and args.bp == 800_000_000:
+    tname = "hbm_traffic.json" if k == 15 else f"hbm_traffic_k{k}.json"
+    tp = os.path.join(ROOT, "profiles", tname)
+    if os.path.exists(tp) and k in (15, 17) and args.bp == 800_000_000:
         with open(tp) as fh:
             tj = json.load(fh)
         if dominant in tj:
             traffic = tj[dominant].get("bytes_per_launch")
             pipeline_traffic = tj.get("_pipeline_bytes_per_step")
-            traffic_source = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run)"
+            traffic_source = f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this run)"
     out = {
         "metric": f"bp/s k-mer counted (k={k}, {world} GPU{'s' if world > 1 else ''})",
         "value": value, "unit": "bp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

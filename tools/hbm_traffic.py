@@ -17,7 +17,7 @@ import sys
 
 PIPELINE = ("k_chunk_l1", "k_chunk_l2", "k_scan_l1_reduce", "k_scan_l1_tiles", "k_scan_l1_apply", "k_scan_l2_reduce",
             "k_scan_l2_tiles", "k_scan_l2_apply", "k_squeeze", "k_walk_sort_count", "k_tally_sum", "k_provision", "k_walk_sort",
-            "k_level1_finish", "k_count2", "k_rows2_scan", "k_scatter2", "k_bucket_count", "k_hist_reduce", "k_apply_side")
+            "k_level1_finish", "k_sample2", "k_rooms2", "k_bases2", "k_starts2", "k_count2", "k_rows2_scan", "k_scatter2", "k_bucket_count", "k_hist_reduce", "k_apply_side")
 
 
 def short(name: str) -> str:
@@ -51,7 +51,7 @@ def main() -> None:
     fetch, write = largest(fetch_csv, "FETCH_SIZE"), largest(write_csv, "WRITE_SIZE")
     out = {
         "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, `bench.py --steps 2 --warmup 0 --no-cpu`), "
-                 "largest dispatch per kernel (= the 800 Mbp k=15 step); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+                 "largest dispatch per kernel (= the 800 Mbp step); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                  "MI355X_MICROARCH.md HBM section (FETCH_SIZE reads half of a wide coalesced stream on gfx950). "
                  "Calibration: k_gram_blk (N=32) vs 34.36 GB algorithmic; k_chunk_l2 vs 0.813 GB FASTA + 0.102 GB lane states + 0.407 GB piece packs. "
                  "The factor 2 is calibrated for 16-byte-per-lane streams only; k_walk_sort reads 4 bytes per lane (0.3 GB of packed "

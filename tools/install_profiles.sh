@@ -13,3 +13,9 @@ cp $O/e2e_cli.json $P/${R}_e2e_cli.json
 cp $O/profile_mix.txt $P/${R}_profile_mix.txt
 cp $O/pmc_sq/sq_counter_collection.csv $P/${R}_pmc_sq_counter_collection.csv
 python tools/hbm_traffic.py $P/${R}_pmc_fetch_counter_collection.csv $P/${R}_pmc_write_counter_collection.csv > $P/hbm_traffic.json
+if [ -f $O/pmc_fetch_k17/fetch_counter_collection.csv ]; then
+  cp $O/pmc_fetch_k17/fetch_counter_collection.csv $P/${R}_k17_pmc_fetch_counter_collection.csv
+  cp $O/pmc_write_k17/write_counter_collection.csv $P/${R}_k17_pmc_write_counter_collection.csv
+  cp $O/stats_k17/ks_kernel_stats.csv $P/${R}_k17_kernel_stats.csv
+  python tools/hbm_traffic.py $P/${R}_k17_pmc_fetch_counter_collection.csv $P/${R}_k17_pmc_write_counter_collection.csv > $P/hbm_traffic_k17.json
+fi

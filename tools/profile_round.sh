@@ -15,6 +15,10 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 echo "fetch done"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o write -- python3 bench.py --steps 2 --warmup 0 --no-cpu --no-e2e > $O/pmc_write.log
 echo "write done"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_k17 -o fetch -- python3 bench.py --k 17 --steps 2 --warmup 0 --no-cpu --no-merge --no-e2e > $O/pmc_fetch_k17.log
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_k17 -o write -- python3 bench.py --k 17 --steps 2 --warmup 0 --no-cpu --no-merge --no-e2e > $O/pmc_write_k17.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_k17 -o ks -- python3 bench.py --k 17 --steps 5 --warmup 1 --no-cpu --no-merge --no-e2e > $O/bench_k17_under_rocprof.json
+echo "k17 passes done"
 timeout -k 10 300 python bench.py --k 17 --no-merge --no-cpu --no-e2e --steps 5 --warmup 1 > $O/bench_k17.json
 PK_TMP=/dev/shm timeout -k 10 400 python tools/e2e_cli.py > $O/e2e_cli.json
 timeout -k 10 300 python tools/profile_mix.py > $O/profile_mix.txt 2>&1
