@@ -362,7 +362,7 @@ struct SliceTally {
 // LEAN (whole-bucket kernel, i.e. dense tables): records of a dense bucket are counted by eight no-return LDS adds and nothing
 // else.  The half-bucket kernel (sparse tables, 64 registers) keeps the form it was tuned with: the same change there moved its
 // register allocation and cost 11 % (5.3 -> 5.9 ms at k = 17).
-template <int T, bool LEAN>
+template <int T, bool LEAN, bool NOREC = false>
 __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start,
                                                   const uint32_t *__restrict__ final_end, uint32_t fb_bits, uint32_t split_bits,
                                                   uint8_t *__restrict__ table8, uint32_t fresh, unsigned long long *__restrict__ hist_rep, uint8_t *smem,
@@ -387,7 +387,10 @@ __device__ __forceinline__ void bucket_count_body(const uint16_t *__restrict__ r
     const uint32_t i_first = base + threadIdx.x * 8;
     uint4 v_first = make_uint4(0, 0, 0, 0);
     if (i_first < min(base + K6_PIECE, end)) v_first = *reinterpret_cast<const uint4 *>(recs + i_first);
-    const bool by_rec = ((end - start) >> split_bits) < n_addr / 4 || n_addr < 16;         // sparse bucket: histogram change from the adds
+    // sparse bucket: histogram change from the adds.  NOREC (k_bucket_count_half_lean: dense tables, 2^15-address buckets)
+    // always takes the slice-difference route, which is right for any bucket of >= 16 addresses: with the choice made at
+    // compile time the record-side code is not in that kernel at all (64 registers, 44 bytes of scratch -> 60, none)
+    const bool by_rec = NOREC ? false : (((end - start) >> split_bits) < n_addr / 4 || n_addr < 16);
     SliceTally tally;
     for (uint32_t i = threadIdx.x; i < 256; i += T) dh[i] = 0;
     if (fresh) {
@@ -573,7 +576,7 @@ void k_bucket_count_half(const uint16_t *__restrict__ recs, const uint32_t *__re
     bucket_count_body<T, false>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, hist_rep, smem, dh, blockIdx.x);
 }
 
-template <int T>
+template <int T, bool FRESH>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_bucket_count_half_lean(const uint16_t *__restrict__ recs, const uint32_t *__restrict__ final_start, const uint32_t *__restrict__ final_end,
                               uint32_t fb_bits, uint32_t split_bits, uint8_t *__restrict__ table8, uint32_t fresh, unsigned long long *__restrict__ hist_rep,
@@ -581,7 +584,9 @@ void k_bucket_count_half_lean(const uint16_t *__restrict__ recs, const uint32_t 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ int dh[256];
     if (flags[0]) return;
-    bucket_count_body<T, true>(recs, final_start, final_end, fb_bits, split_bits, table8, fresh, hist_rep, smem, dh, blockIdx.x);
+    // only ever launched for whole buckets of 2^15 addresses, and per state of the table (first feed after a reset or
+    // not): as literals, the slice loops have compile-time trip counts and the other state's code is not in the kernel
+    bucket_count_body<T, true, true>(recs, final_start, final_end, 15u, 0u, table8, FRESH ? 1u : 0u, hist_rep, smem, dh, blockIdx.x);
 }
 
 // Sparse tables (k = 17: ~3000 records per final bucket of 2^16 addresses) -- BYTE counters.  One workgroup per final
@@ -768,7 +773,8 @@ PartPlan make_part_plan(uint32_t k, uint64_t n_bytes, uint32_t slice_bits, uint3
     // Dense tables of 32-bit k-mers (>= 1 input byte per 8 addresses, e.g. a genome at k = 15): final buckets of 2^15
     // addresses, so that TWO bucket-count workgroups (64 KiB of counters each) share a CU and one's load / count /
     // write-back phases hide behind the other's.  Sparse tables get there by other means (k_bucket_count_half).
-    if (k <= 15 && pl.addr_bits >= 24 && n_bytes >= (((uint64_t)1 << pl.addr_bits) >> 3)) pl.fb_bits = 15;
+    static const uint32_t dense_shift = getenv("PK_DENSE_SHIFT") ? (uint32_t)atoi(getenv("PK_DENSE_SHIFT")) : 3u;
+    if (k <= 15 && pl.addr_bits >= 24 && n_bytes >= (((uint64_t)1 << pl.addr_bits) >> dense_shift)) pl.fb_bits = 15;
     const uint32_t bucket_bits = pl.addr_bits - pl.fb_bits;
     // one level while its digits fit the LDS arrays of the sort kernel that runs level 1 (kmer_fuse.hip: 128 digits for
     // 32-bit k-mers, 512 for 64-bit ones), two levels of about equal width otherwise
@@ -845,7 +851,8 @@ void part_set_attributes() {
     hipFuncSetAttribute((const void *)k_scatter2<true, 512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_bucket_count<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute((const void *)k_bucket_count_half<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    hipFuncSetAttribute((const void *)k_bucket_count_half_lean<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute((const void *)k_bucket_count_half_lean<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute((const void *)k_bucket_count_half_lean<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute((const void *)k_bucket_count_bytes<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, K6_BYTES_LDS);
 }
 
@@ -855,7 +862,7 @@ extern "C" int pk_internal_occupancy(int which) {
     hipError_t e = hipErrorInvalidValue;
     if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_bucket_count_half<1024>, 1024, 65536);
     if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_bucket_count_bytes<1024>, 1024, K6_BYTES_LDS);
-    if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_bucket_count_half_lean<1024>, 1024, 65536);
+    if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_bucket_count_half_lean<1024, true>, 1024, 65536);
     if (which == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_scatter2<true, 512, 32>, 512, SCATTER_LDS_NARROW);
     return e == hipSuccess ? n : -(int)e;
 }
@@ -924,7 +931,8 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     }
     if (ev_part_end) hipEventRecord(ev_part_end, s);
     // sparse tables (few records per 2^16-address bucket, k=17): 2^split workgroups per bucket, see k_bucket_count
-    const bool sparse = pl.fb_bits == 16 && n_bytes / nfb < 8192;
+    static const uint64_t sparse_max = getenv("PK_SPARSE_MAX") ? (uint64_t)atoll(getenv("PK_SPARSE_MAX")) : 8192u;
+    const bool sparse = pl.fb_bits == 16 && n_bytes / nfb < sparse_max;
     const uint32_t split = sparse ? 1u : 0u;
     const size_t part_addrs = (size_t)1 << (pl.fb_bits - split);
     const size_t lds6 = part_addrs * 2 < 64 ? 64 : part_addrs * 2;
@@ -932,8 +940,11 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     const uint32_t n_rows6 = (uint32_t)(nfb << split);
     if (split > 1u) return -3;                                           // the kernels are laid out for whole and half buckets
     if (hipMemsetAsync(bucket_hist, 0, (size_t)HIST_REPLICAS * 256 * 8, s) != hipSuccess) return -2;
-    if (pl.fb_bits == 15)                                                // 64 KiB of counters: two workgroups per CU
-        hipLaunchKernelGGL(k_bucket_count_half_lean<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, k6_start, k6_end, pl.fb_bits, split, table8,
+    if (pl.fb_bits == 15 && fresh)                                       // 64 KiB of counters: two workgroups per CU
+        hipLaunchKernelGGL((k_bucket_count_half_lean<1024, true>), dim3(n_rows6), dim3(1024), lds6, s, final_recs, k6_start, k6_end, pl.fb_bits, split, table8,
+                           fresh ? 1u : 0u, bucket_hist, (const uint32_t *)flags);
+    else if (pl.fb_bits == 15)
+        hipLaunchKernelGGL((k_bucket_count_half_lean<1024, false>), dim3(n_rows6), dim3(1024), lds6, s, final_recs, k6_start, k6_end, pl.fb_bits, split, table8,
                            fresh ? 1u : 0u, bucket_hist, (const uint32_t *)flags);
     else if (split && pk_bytes_enabled())
         hipLaunchKernelGGL(k_bucket_count_bytes<1024>, dim3(nfb), dim3(1024), K6_BYTES_LDS, s, final_recs, k6_start, k6_end, table8, fresh ? 1u : 0u, bucket_hist,
