@@ -27,6 +27,7 @@
 // A bucket that outgrows its room raises a flag (its runs go to a dump area, nothing is overwritten); every
 // later kernel of the feed then returns at once and the host repeats from here with stride 1, i.e. with
 // exact sizes.  Inputs below 1024 chunks are counted exactly straight away.
+#include <cstdlib>
 #include "part_common.h"
 
 namespace pk {
@@ -50,7 +51,7 @@ __device__ __forceinline__ uint32_t smear_up(uint32_t x, uint32_t n) {
 // inside the range.  DEEP (k = 19, 21; always sliced, 1024 x 16): the k-1 bases behind a thread's first one no longer
 // fit one dword, so two are carried and the windows are cut from 96 bits; in front of a slot they come from the slots
 // before it (the chunk state's 32 bits hold 16 bases).
-template <typename KT, bool COUNT, int NT, int PER, int NB, uint32_t HS, bool SLICED, bool DEEP>
+template <typename KT, bool COUNT, int NT, int PER, int NB, uint32_t HS, bool SLICED, bool DEEP, uint32_t KC = 0>
 __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict__ codes, const uint32_t *__restrict__ restarts,
                                                   const uint32_t *__restrict__ n_bases, const L2 *__restrict__ chunk_l2_state,
                                                   PartPlan pl, uint32_t n_items, uint32_t stride, void *__restrict__ out,
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
     ScatterLdsT<NB> &L = *reinterpret_cast<ScatterLdsT<NB> *>(smem);
     uint32_t *tally = reinterpret_cast<uint32_t *>(smem);                 // COUNT only: the sort's LDS is not used then
     __shared__ HotTable<COUNT ? 2u : HS> hot;
-    const uint32_t k = pl.k, km1 = k - 1;
+    const uint32_t k = KC ? KC : pl.k, km1 = k - 1;                       // KC: k as a literal (the k = 15 instantiation)
     if (COUNT) {
         for (uint32_t i = threadIdx.x; i < n_tally; i += NT) tally[i] = 0u;
     } else {
@@ -74,9 +75,13 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
         if (threadIdx.x == 0) hot.used = 0;
         for (uint32_t i = threadIdx.x; i < NB; i += NT) { L.hist[i] = 0; L.run[i] = 0; }
     }
-    const uint32_t B = pl.B1, shift = pl.addr_bits - pl.b1;
+    // unsliced k = 15 / 17 tables always split 7 + rest / 9 + rest (make_part_plan): digit position and count as literals
+    // k as a literal pays (k = 15: 1.39 -> 1.33 ms, k = 17: 2.25 -> 2.03); the digit position as a literal on top of it
+    // pays for the 64-bit kernel only (k = 15: 1.33 -> 1.37 with it)
+    // (the same literals in the level-2 kernel change nothing: 1.213 ms either way)
+    const uint32_t B = KC == 17 ? 512u : pl.B1, shift = KC == 17 ? 25u : pl.addr_bits - pl.b1;
     const uint32_t low_mask = shift >= 32 ? 0xffffffffu : ((1u << shift) - 1u);
-    const bool out16 = pl.b2 == 0;
+    const bool out16 = KC == 17 ? false : pl.b2 == 0;
     const KT mask = (KT)((2u * k >= sizeof(KT) * 8u) ? ~(KT)0 : (((KT)1 << (2u * k)) - 1));
     const KT local_mask = (KT)((pl.addr_bits >= sizeof(KT) * 8u) ? ~(KT)0 : (((KT)1 << pl.addr_bits) - 1));   // SLICED: address inside the range
     const uint32_t t = threadIdx.x;
@@ -489,6 +494,8 @@ constexpr size_t FUSE_LDS_NARROW = offsetof(FuseLdsNarrow, dig);
 // The variants: 32-bit k-mers (k <= 15) as 512 x 32, 64-bit ones (k = 17) as 1024 x 16, each for a whole table or one
 // address slice; k = 19 / 21 deep windows (always a slice).  V(COUNT, ...) names the kernel.
 #define PK_WS_NARROW(COUNT, SLICED) k_walk_sort<uint32_t, COUNT, 512, 32, 128, 512, SLICED, false>
+#define PK_WS_K15(COUNT) k_walk_sort<uint32_t, COUNT, 512, 32, 128, 512, false, false, 15>
+#define PK_WS_K17(COUNT) k_walk_sort<uint64_t, COUNT, 1024, 16, 512, 1024, false, false, 17>
 #define PK_WS_WIDE(COUNT, SLICED) k_walk_sort<uint64_t, COUNT, 1024, 16, 512, 1024, SLICED, false>
 #define PK_WS_DEEP(COUNT) k_walk_sort<uint64_t, COUNT, 1024, 16, 512, 1024, true, true>
 
@@ -496,10 +503,15 @@ void fuse_set_attributes() {
     auto set = [](const void *f, size_t bytes) { hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); };
     set((const void *)PK_WS_NARROW(false, false), FUSE_LDS_NARROW); set((const void *)PK_WS_NARROW(false, true), FUSE_LDS_NARROW);
     set((const void *)PK_WS_NARROW(true, false), 131072); set((const void *)PK_WS_NARROW(true, true), 131072);
+    set((const void *)PK_WS_K15(false), FUSE_LDS_NARROW); set((const void *)PK_WS_K15(true), 131072);
+    set((const void *)PK_WS_K17(false), SCATTER_LDS_WIDE); set((const void *)PK_WS_K17(true), 65536);
     set((const void *)PK_WS_WIDE(false, false), SCATTER_LDS_WIDE); set((const void *)PK_WS_WIDE(false, true), SCATTER_LDS_WIDE);
     set((const void *)PK_WS_WIDE(true, false), 65536); set((const void *)PK_WS_WIDE(true, true), 65536);
     set((const void *)PK_WS_DEEP(false), SCATTER_LDS_WIDE); set((const void *)PK_WS_DEEP(true), 65536);
 }
+
+// PK_K15=0: the generic instantiations for k = 15 / 17 as well (comparison runs)
+static bool pk_k15_enabled() { static const bool on = !(getenv("PK_K15") && atoi(getenv("PK_K15")) == 0); return on; }
 
 template <bool COUNT, typename... Args>
 static void launch_ws(const PartPlan &pl, uint32_t grid, size_t lds, hipStream_t s, Args... args) {
@@ -507,9 +519,11 @@ static void launch_ws(const PartPlan &pl, uint32_t grid, size_t lds, hipStream_t
     if (pl.k > 17) hipLaunchKernelGGL((PK_WS_DEEP(COUNT)), dim3(grid), dim3(1024), lds, s, args...);
     else if (pl.k > 15) {
         if (sliced) hipLaunchKernelGGL((PK_WS_WIDE(COUNT, true)), dim3(grid), dim3(1024), lds, s, args...);
+        else if (pl.k == 17 && pl.b1 == 9 && pk_k15_enabled()) hipLaunchKernelGGL((PK_WS_K17(COUNT)), dim3(grid), dim3(1024), lds, s, args...);
         else hipLaunchKernelGGL((PK_WS_WIDE(COUNT, false)), dim3(grid), dim3(1024), lds, s, args...);
     } else {
         if (sliced) hipLaunchKernelGGL((PK_WS_NARROW(COUNT, true)), dim3(grid), dim3(512), lds, s, args...);
+        else if (pl.k == 15 && pl.b1 == 7 && pk_k15_enabled()) hipLaunchKernelGGL((PK_WS_K15(COUNT)), dim3(grid), dim3(512), lds, s, args...);
         else hipLaunchKernelGGL((PK_WS_NARROW(COUNT, false)), dim3(grid), dim3(512), lds, s, args...);
     }
 }
