@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
     const bool out16 = KC == 17 ? false : pl.b2 == 0;
     const KT mask = (KT)((2u * k >= sizeof(KT) * 8u) ? ~(KT)0 : (((KT)1 << (2u * k)) - 1));
     const KT local_mask = (KT)((pl.addr_bits >= sizeof(KT) * 8u) ? ~(KT)0 : (((KT)1 << pl.addr_bits) - 1));   // SLICED: address inside the range
-    const uint32_t t = threadIdx.x;
+    uint32_t t = threadIdx.x;                                             // COUNT: the thread's place in the slot its WAVE samples (see locate)
     __syncthreads();
     // items: this workgroup's slots (persistent over a contiguous range), or every stride-th slot when sampling
     const uint32_t i_lo = COUNT ? blockIdx.x : blockIdx.x * pl.G1, i_hi = COUNT ? n_items : min(i_lo + pl.G1, n_items);
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
     // stores to be acknowledged by HBM -- a round trip per tile with nothing else in flight.  Addresses are in range
     // for every thread whatever the slot holds; what lies past the base count is masked later.
     struct Fetched { uint32_t nb, prev0, pprev0, r_here, r_before, st_flags, st_bits, cur[NW]; };
-    auto fetch = [&](uint32_t c, Fetched &f) {
+    auto fetch = [&](uint32_t c, uint32_t t, Fetched &f) {
         const uint32_t *cw = codes + (uint64_t)c * SLOT_CODE_WORDS;
         const uint32_t *rw = restarts + (uint64_t)c * SLOT_RST_WORDS;
         f.nb = n_bases[c];
@@ -117,13 +117,31 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
 #pragma unroll
         for (int w = 0; w < NW; w++) asm volatile("" : "+v"(nxt.cur[w]));
     };
-    auto item_chunk = [&](uint32_t it) { return COUNT ? it * stride : it; };
-    if (i_lo < i_hi) fetch(item_chunk(i_lo), nxt);
+    // Which slot, and which thread's place in it, this thread works on in round `it`.  The sort takes whole slots.  The
+    // sampling launch takes one wave's STRETCH (64 threads' bases) of a slot per wave: stretch number g * stride + g % stride
+    // of all stretches, so every second slot contributes an eighth of itself instead of every 16th slot all of itself.
+    // Whole slots made a coarse sample -- a repeat array of a few hundred kbp is one or two sampled slots or none, its
+    // final buckets then outgrow their room and the feed pays the exact re-layout.  Nothing in the tally loop is a
+    // workgroup-wide operation, so the waves may go different ways.
+    auto locate = [&](uint32_t it, uint32_t &c, uint32_t &tt) -> bool {
+        if (!COUNT) { c = it; tt = threadIdx.x; return true; }
+        constexpr uint32_t WPW = NT / 64;
+        const uint64_t g = (uint64_t)it * WPW + (threadIdx.x >> 6);
+        const uint64_t q = stride == 1u ? g : g * stride + g % stride;
+        c = (uint32_t)(q / WPW); tt = (uint32_t)(q % WPW) * 64u + (threadIdx.x & 63u);
+        return q / WPW < pl.n_chunks;
+    };
+    uint32_t c_n = 0, t_n = threadIdx.x;
+    bool ok_n = false;
+    if (i_lo < i_hi) { ok_n = locate(i_lo, c_n, t_n); if (ok_n) fetch(c_n, t_n, nxt); }
     settle();
     for (uint32_t it = i_lo; it < i_hi; it += i_step) {
         const Fetched me = nxt;
-        const uint32_t c = item_chunk(it);
-        if (it + i_step < i_hi) fetch(item_chunk(it + i_step), nxt);
+        const uint32_t c = c_n;
+        const bool ok = ok_n;
+        if (COUNT) t = t_n;
+        if (it + i_step < i_hi) { ok_n = locate(it + i_step, c_n, t_n); if (ok_n) fetch(c_n, t_n, nxt); }
+        if (COUNT && !ok) { settle(); continue; }                            // wave-uniform: past the last slot
         const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)me.nb);           // uniform
         if (nb == 0) { settle(); continue; }
         // ---- this thread's PER bases (NW code dwords), the 16 before them, and the restart bits of all of them

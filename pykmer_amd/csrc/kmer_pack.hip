@@ -17,6 +17,7 @@
 // Per-record tallies (seq_len, number of valid windows, header extent: indexer.py:75-95,349-351) are
 // taken here too, where the text is in hand.  0.38 bytes written per base instead of one 4-byte record;
 // kmer_fuse.hip assembles the k-mers from the slots with no dependence between its threads.
+#include <cstdlib>
 #include "fasta_fsm.h"
 #include "kmer_walk.h"
 #include "pk_kernels.h"
@@ -131,10 +132,11 @@ __device__ __forceinline__ void stage_image(const uint8_t *__restrict__ fasta, u
     else stage_image_tail(fasta, chunk_base, n_bytes, buf);
 }
 
+template <uint32_t KC>                   // k as a literal (0: the argument)
 __global__ __launch_bounds__(WG, 4) void k_squeeze(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
                                                 const LaneState *__restrict__ lane_state, const PiecePack *__restrict__ packs,
                                                 const L2 *__restrict__ chunk_l2_state,
-                                                const uint32_t *__restrict__ chunk_odd, uint32_t k, uint32_t n_chunks, uint32_t chunks_per_wg,
+                                                const uint32_t *__restrict__ chunk_odd, uint32_t k_arg, uint32_t n_chunks, uint32_t chunks_per_wg,
                                                 uint32_t *__restrict__ codes,
                                                 uint32_t *__restrict__ restarts, uint32_t *__restrict__ n_bases,
                                                 DevRec *__restrict__ recs, uint64_t recs_cap, Carry *carry) {
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(WG, 4) void k_squeeze(const uint8_t *__restrict__ f
     __shared__ uint16_t queue[WG];                         // pieces that need the byte-wise machine
     __shared__ uint32_t n_queued;
     __shared__ RecAcc racc;
-    const uint32_t km1 = k - 1;
+    const uint32_t k = KC ? KC : k_arg, km1 = k - 1;
     if (threadIdx.x == 0) n_queued = 0;
     for (uint32_t i = threadIdx.x; i < SLOT_CODE_WORDS + 8; i += WG) slot_codes[i] = 0;
     for (uint32_t i = threadIdx.x; i < SLOT_RST_WORDS + 8; i += WG) slot_rst[i] = 0;
@@ -281,8 +283,13 @@ __global__ __launch_bounds__(WG, 4) void k_squeeze(const uint8_t *__restrict__ f
 void launch_squeeze(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const PiecePack *packs, const L2 *st2,
                     const uint32_t *chunk_odd, uint32_t k, uint32_t n_chunks, uint32_t n_wg, uint32_t chunks_per_wg, uint32_t *codes, uint32_t *restarts, uint32_t *n_bases,
                     DevRec *recs, uint64_t recs_cap, Carry *carry, hipStream_t s) {
-    hipLaunchKernelGGL(k_squeeze, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, packs, st2, chunk_odd, k, n_chunks, chunks_per_wg, codes,
-                       restarts, n_bases, recs, recs_cap, carry);
+    static const bool lit = !(getenv("PK_K15") && atoi(getenv("PK_K15")) == 0);
+    if (lit && k == 15) hipLaunchKernelGGL(k_squeeze<15>, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, packs, st2, chunk_odd, k, n_chunks, chunks_per_wg, codes,
+                                           restarts, n_bases, recs, recs_cap, carry);
+    else if (lit && k == 17) hipLaunchKernelGGL(k_squeeze<17>, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, packs, st2, chunk_odd, k, n_chunks, chunks_per_wg, codes,
+                                                restarts, n_bases, recs, recs_cap, carry);
+    else hipLaunchKernelGGL(k_squeeze<0>, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, packs, st2, chunk_odd, k, n_chunks, chunks_per_wg, codes,
+                            restarts, n_bases, recs, recs_cap, carry);
 }
 
 }  // namespace pk

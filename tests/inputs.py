@@ -100,21 +100,27 @@ def make_input(spec: dict) -> bytes:
     return data
 
 
-def skewed_fasta(n_bp: int, unit_len: int, seed: int = 7, chunk: int = 16384, stride: int = 16) -> bytes:
-    """One record whose 16 KiB text chunks number 0, 16, 32, ... hold uniform random sequence while every other chunk
-    repeats one `unit_len`-base unit (a period the hot-key path does not look for).  The indexer sizes its buckets from
-    every `stride`-th chunk: this text makes that estimate wrong by an order of magnitude on purpose, so the buckets
+def skewed_fasta(n_bp: int, unit_len: int, seed: int = 7, stretch: int = 2048, chunk: int = 16384, stride: int = 16) -> bytes:
+    """One record that defeats the bucket-size sample on purpose.  The indexer sizes its buckets from one wave's stretch
+    of bases (`stretch`: 64 threads x 32 bases for 32-bit k-mers, x 16 for 64-bit ones) out of every `stride` stretches:
+    stretch number q of the text's 16 KiB chunks is sampled iff q % stride == (q // stride) % stride (kmer_fuse.hip,
+    locate).  Here exactly those stretches hold uniform random sequence and everything else repeats one `unit_len`-base
+    unit (a period the hot-key path does not look for), so the estimate is wrong by an order of magnitude, the buckets
     overflow and the exact re-layout has to run."""
     import numpy as np
-    assert n_bp % 60 == 0
+    assert n_bp % 60 == 0 and chunk % stretch == 0
     rng = np.random.default_rng(seed)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     head = b">skewed_against_the_sample\n"
     i = np.arange(n_bp, dtype=np.int64)
     off = len(head) + i + i // 60                              # byte offset of base i: 60 bases and a newline per line
+    slot = off // chunk
+    first = np.searchsorted(slot, np.arange(slot[-1] + 1))     # index of the first base of every chunk
+    q = slot * (chunk // stretch) + (i - first[slot]) // stretch
+    sampled = q % stride == (q // stride) % stride
     unit = acgt[rng.integers(0, 4, size=unit_len)]
     seq = acgt[rng.integers(0, 4, size=n_bp)]
-    rep = (off // chunk) % stride != 0
+    rep = ~sampled
     seq[rep] = unit[i[rep] % unit_len]
     lines = np.empty((n_bp // 60, 61), dtype=np.uint8)
     lines[:, :60] = seq.reshape(-1, 60)

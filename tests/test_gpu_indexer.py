@@ -351,14 +351,15 @@ def test_many_distinct_tandem_repeats(gpu):
 
 @pytest.mark.parametrize("k,unit_len", [(13, 61), (15, 61), (15, 997), (17, 61)])
 def test_bucket_overflow_takes_the_exact_relayout(gpu, k, unit_len):
-    """Bucket rooms come from a sample (every 16th slot of a feed of >= 1024 chunks; k = 17: + a sample of the level-1
-    records).  A text whose sampled chunks look nothing like the rest must overflow them: the overflow flag makes every
+    """Bucket rooms come from a sample (one wave's stretch out of every 16 of a feed of >= 1024 chunks; k = 17: + a sample
+    of the level-1 records).  A text whose sampled chunks look nothing like the rest must overflow them: the overflow flag makes every
     later kernel of the feed return untouched and the host repeats the passes with exact sizes (`relayouts`; for k = 17
     that is the counting pass k_count2 / k_rows2_scan).  Second feed on the same indexer: the same against a table that
     is no longer fresh."""
-    data = inputs.skewed_fasta(20_000_040, unit_len, seed=7 + unit_len)
+    stretch = 1024 if k == 17 else 2048
+    data = inputs.skewed_fasta(20_000_040, unit_len, seed=7 + unit_len, stretch=stretch)
     assert len(data) >= 1024 * 16384
-    more = inputs.skewed_fasta(18_000_000, unit_len + 2, seed=11)
+    more = inputs.skewed_fasta(18_000_000, unit_len + 2, seed=11, stretch=stretch)
     kmers = np.concatenate([oracle.kmer_list(data, k), oracle.kmer_list(more, k)])
     u, c = np.unique(kmers, return_counts=True)
     sat = np.minimum(c, 255).astype(np.uint8)
