@@ -170,7 +170,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
             __hip_atomic_fetch_add(&L.hist[KEEP_DG ? dg[KEEP_DG ? j : 0] : slot_digit(j)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
         // 32 records per thread: every record under its own test (32 digits in registers spill; scratch digits instead of
-        // the tests: 1.42 -> 1.60 ms)
+        // the tests: 1.42 -> 1.60 ms; a wave-uniform path without the tests for waves whose slots are all full: 1.32 -> 1.36)
 #pragma unroll
         for (int j = 0; j < PER; j++) {
             if (FULL || ((okm >> j) & 1u)) __hip_atomic_fetch_add(&L.hist[digit_of(r[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
