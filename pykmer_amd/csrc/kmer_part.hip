@@ -96,7 +96,7 @@ __global__ __launch_bounds__(512) void k_rows2_scan(const uint32_t *__restrict__
 }
 
 // ---- sample2: final-bucket sizes from a sample of the level-1 records (2^15 < final buckets <= 2^18: k = 17, slices of k = 19).
-// One workgroup per level-1 bucket tallies the level-2 digit of every stride2-th group of 64 records in LDS (stride2 = 1:
+// One workgroup per level-1 bucket tallies the level-2 digit of every stride2-th group of 256 records in LDS (stride2 = 1:
 // all of them, i.e. exact).  It replaces the exact counting pass over ALL level-1 records (k_count2: 0.66 ms at k = 17).
 __global__ __launch_bounds__(1024) void k_sample2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ bucket_base,
                                                   const uint32_t *__restrict__ bucket_end, PartPlan pl, uint32_t stride2,
@@ -109,27 +109,33 @@ __global__ __launch_bounds__(1024) void k_sample2(const uint32_t *__restrict__ i
     if (threadIdx.x < 512) h[threadIdx.x] = 0;
     if (threadIdx.x == 0) n_seen = 0;
     __syncthreads();
-    // The sample is every stride2-th GROUP of 64 records (one wave load).  Records of one stretch of text lie together in
+    // The sample is every stride2-th GROUP of 256 records (one wave load).  Records of one stretch of text lie together in
     // a level-1 bucket, and a repeat family can put tens of thousands of records of ONE final bucket into such a
     // stretch: sampled in blocks of 1024 records (as at first) a stretch of 87 K records is 5 or 6 blocks -- an estimate
     // 19 % off, beyond the 12.5 % + 4096 of slack, and which blocks are hit depends on the order the tiles claimed
     // their runs in, i.e. on timing (seen as an occasional re-layout at k = 17 when the level-1 grid changed).
-    const uint32_t n_grp = (hi - lo + 63u) / 64u, n_sgrp = (n_grp + stride2 - 1u) / stride2;
+    // (a group is what one wave loads at 16 bytes per lane: 1 KiB of contiguous records; with 4 bytes per lane -- groups of 64
+    // records, 256 bytes out of every 4 KiB -- the same sample took 0.15 ms instead of 0.06)
+    const uint32_t n_grp = (hi - lo + 255u) / 256u, n_sgrp = (n_grp + stride2 - 1u) / stride2;
     const uint32_t mask = pl.B2 - 1u, shift = pl.fb_bits, w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t mine = 0;
     for (uint32_t s0 = 0; s0 < n_sgrp; s0 += 8u * 16u) {                 // sixteen waves, eight loads in flight per lane
-        uint32_t v[8];
-        bool ok[8];
+        uint4 v[8];
+        uint32_t n_ok[8];                                                // how many of the lane's four records exist
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const uint32_t sg = s0 + (uint32_t)u * 16u + w;
-            const uint64_t i = (uint64_t)lo + (uint64_t)sg * stride2 * 64u + lane;
-            ok[u] = sg < n_sgrp && i < hi;
-            v[u] = ok[u] ? in[i] : 0u;
+            const uint64_t i = (uint64_t)lo + (uint64_t)sg * stride2 * 256u + lane * 4u;      // bucket starts are 16-byte aligned
+            n_ok[u] = (sg < n_sgrp && i < hi) ? (uint32_t)min((uint64_t)4, (uint64_t)hi - i) : 0u;
+            v[u] = n_ok[u] ? *reinterpret_cast<const uint4 *>(in + i) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++)
-            if (ok[u]) { atomicAdd(&h[(v[u] >> shift) & mask], 1u); mine++; }
+        for (int u = 0; u < 8; u++) {
+            const uint32_t r4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (uint32_t e = 0; e < 4; e++)
+                if (e < n_ok[u]) { atomicAdd(&h[(r4[e] >> shift) & mask], 1u); mine++; }
+        }
     }
     for (int d = 32; d; d >>= 1) mine += __shfl_down(mine, d, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&n_seen, mine);
