@@ -921,7 +921,12 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     }
     if (laid_out2) {
         static const uint32_t xcd_affine = getenv("PK_XCD") ? (uint32_t)atoi(getenv("PK_XCD")) : 1u;
-        static const uint32_t grid2_env = getenv("PK_GRID2") ? (uint32_t)atoi(getenv("PK_GRID2")) : 512u;  // 256 CUs x 2
+        // 512 would be the resident two per CU (1.21 ms); more and shorter walks even out the end: 4096 -> 1.17 ms (k = 17: 1.44 -> 1.38).
+        // Measured and kept out: level 2 launched in 2 / 4 / 8 parts (ranges of level-1 buckets) with the bucket count of part p
+        // on a second stream beside level 2 of part p + 1 (one workgroup of each fits a CU's LDS): 1.91 ms for the two
+        // stages back to back, 2.03 / 2.12 / 2.44 overlapped -- every part pays its own ragged end, and the two kernels
+        // do not hide each other (both live on the LDS pipe).
+        static const uint32_t grid2_env = getenv("PK_GRID2") ? (uint32_t)atoi(getenv("PK_GRID2")) : 4096u;
         const uint32_t grid2 = grid2_env < 8u ? 8u : (grid2_env & ~7u);    // a multiple of 8: every XCD class gets the same number of workgroups
         hipLaunchKernelGGL((k_scatter2<true, 512, 32>), dim3(grid2), dim3(512), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
                            bucket_base, bucket_end, (const uint32_t *)nullptr, final_start, pl, out2, cursor2, (const uint32_t *)cap2_end,
