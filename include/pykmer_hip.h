@@ -41,6 +41,10 @@ typedef struct pk_record {
 int pk_version(void);
 int pk_last_error(char *buf, size_t n);
 int pk_device_count(void);
+/* Optional: brings the HIP runtime up on `device` and loads the kernels, so that a command-line host can do this in a
+ * thread while it still parses arguments and maps its input (about 0.2 s that pk_indexer_create / pk_gram* would
+ * otherwise spend).  Has no reference counterpart: indexer.py / merger.py start no device. */
+int pk_warm(int device);
 
 /* ---- plain device buffers, so a host in any language can stage tables in HBM one at a time (a k=17
  * merge holds N x 16 GiB on the device, never on the host) and hand slices to pk_gram_device_partial. */

@@ -8,8 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PK_LIB: another build of the same library (kernel experiments: tools/build_variant.sh); never a CPU stand-in
-LIB_PATH = os.environ.get("PK_LIB") or os.path.join(_HERE, "libpykmer_hip.so")
+from ._rt import LIB_PATH, open_library
 
 PK_OK, PK_ERR_ARG, PK_ERR_HIP, PK_ERR_RECS_CAP, PK_ERR_STATE = 0, -1, -2, -3, -4
 
@@ -20,6 +19,7 @@ _SIGNATURES = {
     "pk_version": (ctypes.c_int, []),
     "pk_last_error": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
     "pk_device_count": (ctypes.c_int, []),
+    "pk_warm": (ctypes.c_int, [ctypes.c_int]),
     "pk_dev_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint64, ctypes.c_int]),
     "pk_dev_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pk_dev_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]),
@@ -62,37 +62,11 @@ class PkError(RuntimeError):
         self.code = code
 
 
-def _share_torch_hip_runtime():
-    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64 with the
-    same SONAMEs as /opt/rocm's; whichever is loaded first serves both, and torch fails ("no ROCm-capable
-    device") if the system copy got in first.  So when torch is installed, pull ITS copies in before our
-    library resolves the SONAMEs (no `import torch` needed); without torch the system runtime is used."""
-    import importlib.util
-    import sys
-    if "torch" in sys.modules:
-        return
-    try:
-        spec = importlib.util.find_spec("torch")
-    except (ImportError, ValueError):
-        spec = None
-    if spec is None or not spec.origin:
-        return
-    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
-    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
-        path = os.path.join(libdir, name)
-        if os.path.exists(path):
-            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
-
-
 def load():
     """Loads the library (building nothing: run pykmer_amd.build or __graft_entry__.build first)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(f"{LIB_PATH} is missing: build it with `python -m pykmer_amd.build` "
-                              "(there is no CPU fallback)")
-        _share_torch_hip_runtime()
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = open_library()
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
@@ -118,6 +92,11 @@ def _as_u8(data) -> np.ndarray:
 
 def device_count() -> int:
     return load().pk_device_count()
+
+
+def warm(device: int = 0) -> None:
+    """pk_warm: HIP start-up and kernel load on `device` (the CLIs call this from a thread while they set up)."""
+    _check(load().pk_warm(device))
 
 
 def mem_info(device: int = 0):

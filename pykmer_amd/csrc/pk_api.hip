@@ -47,6 +47,13 @@ extern "C" int pk_device_count(void) {
     return n;
 }
 
+extern "C" int pk_warm(int device) {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipFree(nullptr));                                // the context
+    pk::part_set_attributes();                               // the code object (first use of a kernel symbol loads it)
+    return PK_OK;
+}
+
 // tools.py:165-167: k > 0 and odd.  One indexer holds at most 2^34 addresses (a 16 GiB table): that is all of k <= 17; beyond
 // (k = 19: 256 GiB, k = 21: 4 TiB -- README.md:51-52 marks both as never run) the address range is cut into 2^slice_bits
 // slices and an indexer counts one of them.

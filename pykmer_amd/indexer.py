@@ -14,7 +14,17 @@ import numpy as np
 from . import _lib
 from .header import Header, gen_checksum
 
+import time
+
 FEED_BYTES = 1 << 30            # host -> device staging granularity
+_T0 = time.perf_counter()
+
+
+def _mark(what: str) -> None:
+    """PK_TIMING=1: where the wall time of a CLI run goes (seconds since this module was imported), on stderr."""
+    if os.environ.get("PK_TIMING"):
+        print(f"[pk timing] {time.perf_counter() - _T0:7.3f} s  {what}", file=sys.stderr)
+
 RESIDENT_LIMIT = 16 << 30       # inputs up to this size (decompressed) are kept in host memory for the header names
 
 
@@ -167,13 +177,16 @@ def count_file(input_file: str, kmer_len: int, device: int = 0, table_file: str 
         """Counts slice s and copies it into table[s * size : (s + 1) * size]; the first slice's pieces feed the hasher
         as they land, later slices are hashed whole once it is their turn (the file is hashed in address order)."""
         src = source if s == 0 else _Input(input_file)
+        _mark("creating the indexer (library load, HIP start-up, table and workspace allocation)")
         with _lib.Indexer(kmer_len, device=devices[s % len(devices)], slice_index=s, n_slices=n_slices) as ix:
             import contextlib
             import io
+            _mark("indexer ready")
             with contextlib.redirect_stdout(io.StringIO()) if s else contextlib.nullcontext():
                 for piece in src.pieces():
                     ix.feed(piece)
             fin = ix.finish()
+            _mark("text counted")
             fin["records"] = ix.records(fin["n_records"]) if s == 0 else None
             fin["timings"] = ix.timings()
             for off in range(0, size, TABLE_SLICE):
@@ -181,6 +194,7 @@ def count_file(input_file: str, kmer_len: int, device: int = 0, table_file: str 
                 ix.table_slice_to_host(part, off)
                 if s == 0:
                     todo.put(part)
+            _mark("table slice on the host")
         return fin
 
     worker = threading.Thread(target=hasher)
@@ -199,8 +213,10 @@ def count_file(input_file: str, kmer_len: int, device: int = 0, table_file: str 
     finally:
         todo.put(None)
         worker.join()
+    _mark("table hashed")
     if table_file is not None:
         table.flush()
+    _mark("table flushed")
     fin["hist256"] = hist
     fin["table_sha256"] = digest.hexdigest()
     fin["n_slices"] = n_slices
@@ -250,10 +266,12 @@ def create_fasta_index(
           f"kmer_size {header.kmer_size:15,d} max_size {header.max_size:15,d}")
     print("  indexing finished. creating header")
     checksums = {"input": input_sum.result(), "output": fin["table_sha256"]}
+    _mark("input hashed")
     pool.shutdown()
     header.write_metadata_index_tmp_file(hist256=fin["hist256"], checksums=checksums)   # asserts num_kmers and chromosomes (tools.py:367-368)
     print("renaming")
     os.rename(header.index_tmp_file, header.index_file_root)  # indexer.py:412
+    _mark("files renamed")
     print("done")
     return header
 
