@@ -7,6 +7,10 @@
 #include "fasta_fsm.h"
 #include "pk_kernels.h"
 
+#ifndef PK_LB_L2
+#define PK_LB_L2 7   // waves per SIMD the structure kernel is compiled for (72 registers; 6: 0.425 ms on the genome and 0.73 on 400 k reads, 7: 0.412 and 0.66; 4, 5 and 8: 0.44)
+#endif
+
 namespace pk {
 
 // ------------------------------------------------------------------ per-chunk summaries --------
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(WG) void k_chunk_l1(const uint8_t *__restrict__ fas
 // of such pieces again.  Pieces with a header, a blank or a control byte -- or that start inside a header line -- need the
 // byte-wise machines, which cost a wave the same for one lane as for 64: those pieces are queued and worked off 64 per
 // wave pass (a read set has a header every kilobase; each wave then held a few such pieces and every wave took both machines).
-__global__ __launch_bounds__(WG, 6) void k_chunk_l2(const uint8_t *__restrict__ fasta, uint64_t n_bytes,
+__global__ __launch_bounds__(WG, PK_LB_L2) void k_chunk_l2(const uint8_t *__restrict__ fasta, uint64_t n_bytes,
                                                  const L1 *__restrict__ chunk_l1_state, L2 *__restrict__ chunk_l2,
                                                  LaneState *__restrict__ lane_state, PiecePack *__restrict__ packs,
                                                  uint32_t *__restrict__ chunk_odd, uint32_t km1) {

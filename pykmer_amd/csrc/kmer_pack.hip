@@ -22,6 +22,10 @@
 #include "kmer_walk.h"
 #include "pk_kernels.h"
 
+#ifndef PK_LB_SQ
+#define PK_LB_SQ 4   // waves per SIMD the squeeze kernel is compiled for (3, 5, 6 and 8 all give 0.31 ms instead of 0.21)
+#endif
+
 namespace pk {
 
 // exclusive scan of a small count over the 256 lanes of the workgroup (sh: 4 words; one barrier)
@@ -133,7 +137,7 @@ __device__ __forceinline__ void stage_image(const uint8_t *__restrict__ fasta, u
 }
 
 template <uint32_t KC>                   // k as a literal (0: the argument)
-__global__ __launch_bounds__(WG, 4) void k_squeeze(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
+__global__ __launch_bounds__(WG, PK_LB_SQ) void k_squeeze(const uint8_t *__restrict__ fasta, uint64_t n_bytes, uint64_t stream_off,
                                                 const LaneState *__restrict__ lane_state, const PiecePack *__restrict__ packs,
                                                 const L2 *__restrict__ chunk_l2_state,
                                                 const uint32_t *__restrict__ chunk_odd, uint32_t k_arg, uint32_t n_chunks, uint32_t chunks_per_wg,
