@@ -611,9 +611,9 @@ void k_bucket_count_bytes(const uint16_t *__restrict__ recs, const uint32_t *__r
                           uint8_t *__restrict__ table8, uint32_t fresh, unsigned long long *__restrict__ hist_rep,
                           const uint32_t *__restrict__ flags) {
     // 64 KiB: the slice, then the 256 histogram bins and the wrap flag.  No static LDS in this kernel: it would sit in
-    // front of the slice, and with the slice's base off a 128-byte line every 16-byte LDS access of the zeroing and the
-    // copy-out ran into bank conflicts (a 4-byte static pushed the base to 1040: 1.5 G conflict cycles per launch against
-    // 0.3 G, 6.6 ms against 5.2 for the kernel this one replaces).
+    // front of the slice and push its base off a 128-byte line (a 4-byte static made it 1040), which the 16-byte LDS
+    // accesses of the zeroing and the copy-out pay for with bank conflicts (6.6 -> 6.4 ms at the time; the large cost of
+    // the first version was the lanes without records, see the record loop below).
     extern __shared__ __attribute__((aligned(128))) uint8_t smem[];
     constexpr uint32_t N_ADDR = 65536u;
     int *dh = reinterpret_cast<int *>(smem + N_ADDR);
@@ -646,7 +646,9 @@ void k_bucket_count_bytes(const uint16_t *__restrict__ recs, const uint32_t *__r
         bool wrapped = false;
         for (uint32_t p0 = base; p0 < end; p0 += (uint32_t)T * 8u) {    // at most three rounds
             const uint32_t i = p0 + threadIdx.x * 8;
-            if (i >= end) continue;                                      // lanes without records stay out of LDS (their adds would all meet on one address)
+            // lanes without records stay out of LDS: their eight adds (of zero) would all meet on address 0, a 64-way
+            // same-address conflict per wave instruction -- 1.5 G LDS conflict cycles per launch against 0.3 G, 6.4 ms against 3.6
+            if (i >= end) continue;
             if (p0 != base) v = *reinterpret_cast<const uint4 *>(recs + i);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
             const bool interior = i >= start && i + 8u <= end;           // nearly every lane
