@@ -35,6 +35,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.pk_version() == 2
 
 
+def test_numpy_free_loader_serves_the_same_library():
+    """pykmer_amd/_rt.py (ctypes only) is what the CLIs warm the device with before numpy is imported: it must open the
+    very library the binding uses, and importing it must not pull numpy in."""
+    import subprocess
+    import sys
+    from pykmer_amd import _rt
+    assert _rt.LIB_PATH == _lib.LIB_PATH
+    assert _rt.open_library() is _rt.open_library()
+    assert hasattr(_rt.open_library(), "pk_warm")
+    code = "import sys; sys.path.insert(0, %r); from pykmer_amd import _rt; assert 'numpy' not in sys.modules; print(_rt.LIB_PATH)" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == _lib.LIB_PATH
+
+
 def test_argument_errors_need_no_gpu():
     lib = _lib.load()
     buf = ctypes.create_string_buffer(256)
