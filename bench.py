@@ -136,6 +136,11 @@ def main():
                     help="threads of the all-cores CPU legs (default 0 = every core this process may run on)")
     args = ap.parse_args()
 
+    # the bench measures the library as shipped: no alternate build, no kernel switches (experiments: tools/)
+    switches = [v for v in ("PK_LIB", "PK_K15", "PK_K6_BYTES", "PK_GRAM_MW", "PK_DENSE_SHIFT", "PK_WG1", "PK_GRID2", "PK_XCD", "PK_SPARSE_MAX")
+                if v in os.environ]
+    assert not switches, f"experiment switches set in the environment: {switches}"
+
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
@@ -256,9 +261,12 @@ def main():
     # ---- secondary: N x N merge scan over N tables resident in HBM, address range sharded over ranks
     # (N=13: BASELINE configs[2]; N=32: configs[4], the LDS-tiled kernel).  Not part of `value`.
     def merge_section(N):
+        # the product path: pykmer_amd.merger.pair_matrix on tables that stayed in HBM (ResidentTable) -- the same function
+        # merger.py calls; with several ranks it scans this rank's address slice into an accumulator in HBM and sums the
+        # N x N partials with one all-reduce over RCCL (merger.py:137-178's pool, replaced)
+        from pykmer_amd import merger
         n = 4 ** k
-        lo = (n // world) * rank
-        hi = n if rank == world - 1 else (n // world) * (rank + 1)
+        lo, hi = merger.address_slice(n, rank, world)
         slices = []
         for i in range(N):
             fa, _ = synth.family(i, args.merge_bp)
@@ -268,29 +276,41 @@ def main():
             sl = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
             ix.table_slice_to_device(sl.data_ptr(), lo, hi - lo)   # this rank's address slice stays in HBM
             slices.append(sl)
-        d_pair = torch.zeros(N * N, dtype=torch.int64, device=dev)
+        tabs = [merger.ResidentTable(sl.data_ptr(), hi - lo, n, device=local, first=lo) for sl in slices]
         ptrs = [s.data_ptr() for s in slices]
-        best, kern = None, None
-        for rep in range(4):
-            barrier()
-            t0 = time.perf_counter()
-            pair, ksec = _lib.gram_device_partial(ptrs, hi - lo, 1, 255, device=local, dev_pair_out=d_pair.data_ptr())
-            if dist is not None:
-                dist.all_reduce(d_pair)                            # RCCL sum of the N x N partials over xGMI
-            barrier()
-            dt = time.perf_counter() - t0
-            if rep and (best is None or dt < best):
-                best, kern = dt, ksec
-        if dist is not None:                                       # slowest rank defines the merge time
-            tt = torch.tensor([best], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            best = float(tt.item())
-        total = d_pair.view(N, N).cpu().numpy()
+        group = True if dist is not None else None
+
+        def timed(windows, reps=4):
+            best, kern, pairs = None, None, None
+            for rep in range(reps):
+                barrier()
+                t0 = time.perf_counter()
+                stats = {}
+                pairs = merger.pair_matrix(tabs, windows, devices=(local,), group=group, stats=stats)
+                barrier()
+                dt = time.perf_counter() - t0
+                if rep and (best is None or dt < best):
+                    best, kern = dt, stats.get("kernel_seconds")
+            if dist is not None:                                   # slowest rank defines the merge time
+                tt = torch.tensor([best], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                best = float(tt.item())
+            return best, kern, pairs
+        best, kern, pairs = timed([(1, 255)])
+        total = pairs[0].astype(np.int64)
         assert all(total[i, j] <= min(total[i, i], total[j, j]) for i in range(N) for j in range(i + 1, N))
         res = {"n_tables": N, "k": k, "seconds": best, "kernel_seconds_rank0": kern, "algorithmic_bytes": N * n,
                "kernel_GBps_aggregate": N * n / kern / 1e9 if world == 1 else None,
                "end_to_end_GBps_aggregate": N * n / best / 1e9,
-               "sharding": f"address range / {world} + all_reduce(N*N u64)" if world > 1 else "single GPU"}
+               "sharding": f"address range / {world} + all_reduce(N*N u64)" if world > 1 else "single GPU",
+               "path": "pykmer_amd.merger.pair_matrix (ResidentTable inputs)"}
+        # threshold sweep (README.md:57-61: the reference re-merges per threshold): eight windows from one pass over the tables
+        sweep = [(1, 255), (2, 255), (3, 255), (4, 255), (5, 255), (8, 255), (1, 50), (2, 20)]
+        s_best, s_kern, s_pairs = timed(sweep, reps=3)
+        assert np.array_equal(s_pairs[0].astype(np.int64), total)
+        res["sweep8_seconds"] = s_best
+        res["sweep8_kernel_seconds_rank0"] = s_kern
+        res["sweep8_over_one_scan"] = (s_kern / kern) if (kern and s_kern) else None
         if rank == 0 and world == 1 and not args.no_cpu:
             # CPU baseline of the merge: the reference's pair loop (tools.py:439-493 per pair, merger.py:137-153 over a
             # pool) restated in C, on a bounded slice of the address range of the SAME tables; the pair loop's cost is

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define PK_ABI_VERSION 2
+#define PK_ABI_VERSION 3
 
 enum {
     PK_OK = 0,
@@ -88,7 +88,8 @@ int pk_indexer_reset(pk_indexer *ix);                       /* zero the table, f
 /* Feed the next n_bytes of the FASTA text.  Chunks may split lines, records and k-mers anywhere.   */
 int pk_indexer_feed(pk_indexer *ix, const uint8_t *host_fasta, uint64_t n_bytes);
 /* Same, but the bytes already sit in device memory on the indexer's device (16-byte aligned).  Work runs on
- * the indexer's own stream; the call returns when the feed has been counted. */
+ * the indexer's own stream; the call returns when the feed has been counted.  Any size: the library cuts the text into
+ * pieces of at most 2 GiB (record positions inside one piece are 32-bit). */
 int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uint64_t n_bytes);
 /* Close the last record and report the totals.  hist256_out[v] = number of table entries equal to v
  * (the histogram is kept in HBM while counting, so this makes no pass over the table).              */
@@ -144,7 +145,23 @@ int pk_gram_device_partial(const void *const *dev_tables, int N, uint64_t n_slic
  * sub-slices, and the accumulator is what the RCCL all-reduce sums across ranks (merger.py:163-178). */
 int pk_gram_device_accumulate(const void *const *dev_tables, int N, uint64_t n_slice, int min_count,
                               int max_count, void *dev_pair_accum, int device, double *kernel_seconds_out);
+/* The same for n_windows validity windows at once (threshold sweeps: the reference re-runs the whole merge per
+ * --min-count / --max-count, README.md:57-61; the compare itself is tools.py:473-475).  dev_pair_accum holds
+ * n_windows x N x N u64, block w for (min_counts[w], max_counts[w]); the staged slices are streamed once per group of up
+ * to eight windows (N <= 16; five for N <= 24, three for N <= 32, one beyond), not once per window. */
+int pk_gram_device_accumulate_windows(const void *const *dev_tables, int N, uint64_t n_slice, const int *min_counts,
+                                      const int *max_counts, int n_windows, void *dev_pair_accum, int device,
+                                      double *kernel_seconds_out);
 int pk_gram_expand(const uint64_t *pair, int N, uint64_t *matrix_out);
+
+/* ---- diagnostics (tools/, tests/): no reference counterpart, no effect on any result.
+ * pk_diag_occupancy: workgroups per CU the runtime grants kernel `which` (0 k_bucket_count_half, 1 k_bucket_count_bytes,
+ * 2 k_bucket_count_half_lean, 3 k_scatter2<claim>); negative = HIP error.
+ * pk_diag_plan: the partition plan of ONE feed of n_bytes (0 = the largest piece a feed is cut into) at kmer_len k:
+ * out = { largest piece, level-1 record capacity, final-bucket record capacity, level-1 buckets, level-2 digits,
+ * address bits per final bucket, 16 KiB chunks, 1 if every record position fits 32 bits }. */
+int pk_diag_occupancy(int which);
+int pk_diag_plan(int k, uint64_t n_bytes, uint64_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,10 @@ from pykmer_amd.indexer import main  # noqa: E402
 
 if __name__ == "__main__":
     main()
-    # everything is written and renamed: leave without tearing down the interpreter and the HIP runtime (~0.15 s)
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
+    # Everything is written, closed and renamed at this point.  PK_FAST_EXIT=1 leaves without tearing down the
+    # interpreter and the HIP runtime (~0.15 s of a 0.9 s run): no atexit handlers, no flush of file objects other
+    # than the two below -- so it is an opt-in for batch loops, not the default.
+    if os.environ.get("PK_FAST_EXIT") == "1":
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)

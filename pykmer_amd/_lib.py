@@ -49,7 +49,11 @@ _SIGNATURES = {
                                                ctypes.POINTER(ctypes.c_double)]),
     "pk_gram_device_accumulate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    "pk_gram_device_accumulate_windows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
+                                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "pk_gram_expand": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "pk_diag_occupancy": (ctypes.c_int, [ctypes.c_int]),
+    "pk_diag_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -277,6 +281,27 @@ def gram_device_accumulate(dev_ptrs, n_slice: int, dev_pair_accum: int, min_coun
     _check(load().pk_gram_device_accumulate(ptrs, N, n_slice, min_count, max_count, ctypes.c_void_p(dev_pair_accum), device,
                                             ctypes.byref(secs)))
     return secs.value
+
+
+def gram_device_accumulate_windows(dev_ptrs, n_slice: int, dev_pair_accum: int, windows, device: int = 0) -> float:
+    """pk_gram_device_accumulate_windows: adds one slice's tallies for every (min_count, max_count) of `windows` to a
+    W x N x N u64 accumulator in HBM -- one pass over the slices per group of windows; returns kernel seconds."""
+    N, W = len(dev_ptrs), len(windows)
+    ptrs = (ctypes.c_void_p * N)(*dev_ptrs)
+    mins = (ctypes.c_int * W)(*[int(w[0]) for w in windows])
+    maxs = (ctypes.c_int * W)(*[int(w[1]) for w in windows])
+    secs = ctypes.c_double(0)
+    _check(load().pk_gram_device_accumulate_windows(ptrs, N, n_slice, mins, maxs, W, ctypes.c_void_p(dev_pair_accum), device,
+                                                    ctypes.byref(secs)))
+    return secs.value
+
+
+def diag_plan(k: int, n_bytes: int = 0) -> dict:
+    """pk_diag_plan: the partition plan of one feed (n_bytes = 0: the largest piece a feed is cut into)."""
+    out = np.zeros(8, dtype=np.uint64)
+    _check(load().pk_diag_plan(k, n_bytes, out.ctypes.data))
+    names = ("feed_max", "capacity1", "capacity2", "B1", "B2", "fb_bits", "n_chunks", "fits_u32")
+    return {n: int(v) for n, v in zip(names, out)}
 
 
 def gram_expand(pair: np.ndarray) -> np.ndarray:

@@ -4,8 +4,10 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PK_LIB: another build of the same library (kernel experiments: tools/build_variant.sh); never a CPU stand-in
+# PK_LIB: another build of the same library (kernel experiments: tools/build_variant.sh); never a CPU stand-in --
+# open_library() refuses one that does not answer pk_version() with this ABI or lacks the device entry points
 LIB_PATH = os.environ.get("PK_LIB") or os.path.join(_HERE, "libpykmer_hip.so")
+ABI_VERSION = 3                      # PK_ABI_VERSION of include/pykmer_hip.h
 
 _handle = None
 
@@ -40,7 +42,16 @@ def open_library():
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -m pykmer_amd.build` "
                               "(there is no CPU fallback)")
         _share_torch_hip_runtime()
-        _handle = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        missing = [n for n in ("pk_version", "pk_warm", "pk_device_count", "pk_indexer_feed_device", "pk_gram_device_partial")
+                   if not hasattr(lib, n)]
+        if missing:
+            raise ImportError(f"{LIB_PATH} is not a build of libpykmer_hip.so: no {', '.join(missing)}")
+        lib.pk_version.restype, lib.pk_version.argtypes = ctypes.c_int, []
+        if lib.pk_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} speaks ABI {lib.pk_version()}, this package needs {ABI_VERSION}: rebuild it "
+                              "(python -m pykmer_amd.build)")
+        _handle = lib
     return _handle
 
 

@@ -125,12 +125,56 @@ def decompress_file(path: str, expected_size: int = None, threads: int = DEFAULT
     return data
 
 
+_INDEX_CACHE = {}
+
+
+def block_index(path: str):
+    """(compressed offsets, compressed sizes, uncompressed offsets [n_blocks + 1]) of every data block of a BGZF file, as
+    int64 arrays.  From the `.gzi` beside the file when there is one (gzireader.py:12-34 layout: every block but the
+    first), else from one walk over the block headers (no inflation).  Cached per (path, size, mtime): a sharded merge
+    asks for many ranges of the same file."""
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_size, st.st_mtime_ns)
+    hit = _INDEX_CACHE.get(key)
+    if hit is not None:
+        return hit
+    raw = np.memmap(path, dtype=np.uint8, mode="r")
+    buf = memoryview(raw)
+    gzi = path + ".gzi"
+    if os.path.exists(gzi) and os.path.getmtime(gzi) >= st.st_mtime:
+        entries = [(0, 0)] + read_gzi(gzi)
+        c_offs = np.array([c for c, _ in entries], dtype=np.int64)
+        u_offs = np.array([u for _, u in entries], dtype=np.int64)
+        last = int(c_offs[-1])                               # the last indexed block: its size is in its own header
+        last_size = struct.unpack_from("<H", buf, last + 16)[0] + 1
+        c_sizes = np.append(np.diff(c_offs), last_size)
+        last_isize = struct.unpack_from("<I", buf, last + last_size - 4)[0]
+        u_offs = np.append(u_offs, u_offs[-1] + last_isize)
+    else:
+        blocks = scan_blocks(buf)
+        if not blocks:
+            raise OSError(f"{path}: not a BGZF file")
+        c_offs = np.array([o for o, _ in blocks], dtype=np.int64)
+        c_sizes = np.array([z for _, z in blocks], dtype=np.int64)
+        isizes = np.array([struct.unpack_from("<I", buf, o + z - 4)[0] for o, z in blocks], dtype=np.int64)
+        keep = isizes > 0                                    # the empty end-of-file block (and any other empty block) is no data
+        if keep.any():
+            c_offs, c_sizes, isizes = c_offs[keep], c_sizes[keep], isizes[keep]
+        else:
+            c_offs, c_sizes, isizes = c_offs[:1], c_sizes[:1], isizes[:1]
+        u_offs = np.concatenate(([0], np.cumsum(isizes)))
+    if len(_INDEX_CACHE) > 64:
+        _INDEX_CACHE.clear()
+    _INDEX_CACHE[key] = (c_offs, c_sizes, u_offs)
+    return _INDEX_CACHE[key]
+
+
 def decompress_range(path: str, lo: int, hi: int, threads: int = DEFAULT_THREADS) -> Tuple[np.ndarray, int]:
     """Uncompressed bytes [lo, hi) of a gzip / BGZF file -> (array, bytes inflated to get them).
 
-    BGZF: the block list comes from the `.gzi` beside the file when there is one (gzireader.py:12-34 layout),
-    otherwise from walking the block headers (18 bytes each, no inflation); only the blocks overlapping the
-    range are inflated, in parallel.  Any other gzip stream is read sequentially up to `hi`."""
+    BGZF: the blocks overlapping the range are found in the (cached) block index -- the `.gzi` beside the file, or one
+    walk over the block headers -- and only they are inflated, in parallel.  Any other gzip stream is read
+    sequentially up to `hi`."""
     if hi <= lo:
         return np.zeros(0, dtype=np.uint8), 0
     if not is_bgzf(path):
@@ -143,43 +187,50 @@ def decompress_range(path: str, lo: int, hi: int, threads: int = DEFAULT_THREADS
                 left -= len(got)
             data = np.frombuffer(fh.read(hi - lo), dtype=np.uint8)
         return data, hi
+    c_offs, c_sizes, u_offs = block_index(path)
+    if hi > int(u_offs[-1]):
+        raise OSError(f"{path}: ends before byte {hi}")
+    first = int(np.searchsorted(u_offs, lo, side="right")) - 1
+    end = int(np.searchsorted(u_offs, hi, side="left"))       # blocks [first, end) overlap [lo, hi)
     raw = np.memmap(path, dtype=np.uint8, mode="r")
     buf = memoryview(raw)
-    gzi = path + ".gzi"
-    if os.path.exists(gzi):
-        entries = [(0, 0)] + read_gzi(gzi)                   # every block's (compressed, uncompressed) start
-        c_offs = [c for c, _ in entries]
-        u_offs = [u for _, u in entries]
-        first = max(0, int(np.searchsorted(u_offs, lo, side="right")) - 1)
-        blocks, offs = [], []
-        i = first
-        while i < len(entries) and u_offs[i] < hi:
-            c_end = c_offs[i + 1] if i + 1 < len(entries) else None
-            if c_end is None:                                # last indexed block: its size is in its own header
-                c_end = c_offs[i] + struct.unpack_from("<H", buf, c_offs[i] + 16)[0] + 1
-            blocks.append((c_offs[i], c_end - c_offs[i]))
-            offs.append(u_offs[i])
-            i += 1
-    else:
-        blocks, offs, u = [], [], 0
-        for off, size in scan_blocks(buf):
-            isize = struct.unpack_from("<I", buf, off + size - 4)[0]
-            if u + isize > lo and u < hi:
-                blocks.append((off, size))
-                offs.append(u)
-            u += isize
-            if u >= hi:
-                break
-    if not blocks:
-        raise OSError(f"{path}: range [{lo}, {hi}) is outside the file")
-    sizes = [struct.unpack_from("<I", buf, off + size - 4)[0] for off, size in blocks]
-    base = offs[0]
-    span = np.empty(offs[-1] + sizes[-1] - base, dtype=np.uint8)
+    base = int(u_offs[first])
+    span = np.empty(int(u_offs[end]) - base, dtype=np.uint8)
     with ThreadPoolExecutor(max_workers=threads) as pool:
-        list(pool.map(lambda i: _inflate_block(buf, blocks[i][0], blocks[i][1], span, offs[i] - base), range(len(blocks))))
-    if base + span.size < hi:
-        raise OSError(f"{path}: ends before byte {hi}")
+        list(pool.map(lambda i: _inflate_block(buf, int(c_offs[i]), int(c_sizes[i]), span, int(u_offs[i]) - base), range(first, end)))
     return span[lo - base: hi - base], int(span.size)
+
+
+def iter_pieces(path: str, piece_bytes: int, threads: int = DEFAULT_THREADS):
+    """The inflated stream of a BGZF file in pieces of about `piece_bytes` (whole blocks), in order.  Piece i + 1 is
+    inflated (block-parallel, on `threads` host threads) while the caller still works on piece i -- the indexer feeds
+    piece i to the GPU meanwhile -- so a bgzipped FASTA never sits inflated in host memory as a whole."""
+    c_offs, c_sizes, u_offs = block_index(path)
+    n_blocks = len(c_offs)
+    raw = np.memmap(path, dtype=np.uint8, mode="r")
+    buf = memoryview(raw)
+    cuts, i = [], 0
+    while i < n_blocks:
+        j = int(np.searchsorted(u_offs, u_offs[i] + piece_bytes, side="right")) - 1
+        j = min(n_blocks, max(j, i + 1))
+        cuts.append((i, j))
+        i = j
+
+    def inflate(cut, pool):
+        i, j = cut
+        base = int(u_offs[i])
+        out = np.empty(int(u_offs[j]) - base, dtype=np.uint8)
+        return out, [pool.submit(_inflate_block, buf, int(c_offs[b]), int(c_sizes[b]), out, int(u_offs[b]) - base) for b in range(i, j)]
+
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        ahead = inflate(cuts[0], pool) if cuts else None
+        for n in range(len(cuts)):
+            out, futures = ahead
+            for f in futures:
+                f.result()
+            ahead = inflate(cuts[n + 1], pool) if n + 1 < len(cuts) else None   # runs while the caller holds `out`
+            if out.size:
+                yield out
 
 
 def is_bgzf(path: str) -> bool:

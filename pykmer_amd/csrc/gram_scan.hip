@@ -190,6 +190,202 @@ __global__ __launch_bounds__(MAXT) void k_gram_blk(const uint8_t *const *__restr
     }
 }
 
+// ------------------------------------------------------------------ several windows in one pass --
+// A threshold sweep (README.md:57-61: every --min-count / --max-count costs the reference a whole re-merge) asks for
+// the same N x N tallies under W validity windows.  One pass over the tables serves them all: the 32 bytes a lane
+// loads are turned into eight BIT PLANES (an 8 x 8 bit transpose across the eight dwords: 48 bit-field inserts), on
+// which "count >= t" is a ripple comparator -- one three-input boolean per bit, t uniform -- so a window costs 8 or 17
+// vector instructions per 32 addresses instead of the ~50 of the SWAR byte compares.  The masks of all windows go to
+// LDS ([window][table][word]); a (window, pair block) combination is a wave's slot exactly like a pair block above.
+// One workgroup per CU (the accumulators of two slots + the masks of up to 8 windows), so the next tile's loads are
+// issued before the tallies of the current one and land during them.
+struct WindowSet {     // byte w of each word belongs to window w (bytes of one scalar register: no indexed kernel arguments)
+    int W;
+    unsigned long long lo;     // min_count (>= 1)
+    unsigned long long hi1;    // max_count + 1, or 0 when max_count = 255 (no upper bound)
+    unsigned long long out;    // which N x N block of the output the window's tallies are added to
+};
+
+// rows x[0..7] (dwords), columns = bit positions inside each byte: transposed per byte lane, so that afterwards bit i
+// of byte j of x[b] is bit b of byte j of the old x[i]
+__device__ __forceinline__ void bit_transpose8(uint32_t (&x)[8]) {
+    auto swap = [](uint32_t &r0, uint32_t &r1, uint32_t m, uint32_t s) {
+        const uint32_t n0 = (r0 & m) | ((r1 << s) & ~m), n1 = ((r0 >> s) & m) | (r1 & ~m);
+        r0 = n0; r1 = n1;
+    };
+    swap(x[0], x[1], 0x55555555u, 1); swap(x[2], x[3], 0x55555555u, 1); swap(x[4], x[5], 0x55555555u, 1); swap(x[6], x[7], 0x55555555u, 1);
+    swap(x[0], x[2], 0x33333333u, 2); swap(x[1], x[3], 0x33333333u, 2); swap(x[4], x[6], 0x33333333u, 2); swap(x[5], x[7], 0x33333333u, 2);
+    swap(x[0], x[4], 0x0f0f0f0fu, 4); swap(x[1], x[5], 0x0f0f0f0fu, 4); swap(x[2], x[6], 0x0f0f0f0fu, 4); swap(x[3], x[7], 0x0f0f0f0fu, 4);
+}
+// mask of the addresses whose count is >= t (t uniform, 1..255), from the bit planes: from the lowest bit up,
+// ge = t_b ? (p_b & ge) : (p_b | ge)
+__device__ __forceinline__ uint32_t planes_ge(const uint32_t (&p)[8], uint32_t t) {
+    uint32_t ge = ~0u;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const uint32_t nt = 0u - ((~t >> b) & 1u);                       // uniform: all ones where t_b = 0
+        // majority(p_b, ge, nt) in one instruction; written out, the compiler selects between p & ge and p | ge (3 instructions)
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe8" : "=v"(ge) : "v"(p[b]), "v"(ge), "s"(nt));
+    }
+    return ge;
+}
+
+template <int SLOTS, int TW, int ITEMS, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_gram_mw(const uint8_t *const *__restrict__ tables, int N, uint64_t n, WindowSet ws,
+                                                 unsigned long long *__restrict__ pair) {
+    extern __shared__ uint32_t masks[];                 // [W][NBT][TW]
+    constexpr bool PACK = SLOTS > 1;
+    const int NBT = ((N + BLK - 1) / BLK) * BLK;
+    const int nthreads = blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NB = NBT / BLK, n_pb = NB * (NB + 1) / 2;  // pair blocks (a, b), a <= b, row by row
+    int bi[SLOTS], bj[SLOTS], win[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+        const int c = wave * SLOTS + s;                  // combination = (window, pair block)
+        const bool on = c < ws.W * n_pb;
+        int a = 0, rem = c % n_pb;
+        while (rem >= NB - a) { rem -= NB - a; a++; }
+        win[s] = on ? c / n_pb : -1;
+        bi[s] = on ? a : -1;
+        bj[s] = on ? a + rem : -1;
+    }
+    constexpr int AJ = PACK ? BLK / 2 : BLK;
+    uint32_t acc[SLOTS][BLK][AJ];
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++)
+#pragma unroll
+        for (int i = 0; i < BLK; i++)
+#pragma unroll
+            for (int j = 0; j < AJ; j++) acc[s][i][j] = 0;
+
+    const uint64_t n_words = n_words_for(n);
+    const uint64_t n_tiles = (n_words + TW - 1) / TW;
+    const int items = NBT * TW;
+    uint4 ra[ITEMS], rb[ITEMS];
+    auto fetch = [&](uint64_t tile) {
+        const uint64_t w0 = tile * TW;
+#pragma unroll
+        for (int m = 0; m < ITEMS; m++) {
+            const int q = threadIdx.x + m * nthreads;
+            const int t = __builtin_amdgcn_readfirstlane(q / TW), w = q % TW;
+            ra[m] = make_uint4(0, 0, 0, 0); rb[m] = ra[m];
+            if (q < items && t < N && w0 + w < n_words && tile < n_tiles) load_word(tables[t], w0 + w, n, ra[m], rb[m]);
+        }
+    };
+    fetch(blockIdx.x);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        // phase 1: the tile's (table, word) items -> one mask per window in LDS
+#pragma unroll
+        for (int m = 0; m < ITEMS; m++) {
+            const int q = threadIdx.x + m * nthreads;
+            if (q >= items) continue;
+            uint32_t p[8] = {ra[m].x, ra[m].y, ra[m].z, ra[m].w, rb[m].x, rb[m].y, rb[m].z, rb[m].w};
+            bit_transpose8(p);
+            uint32_t ge_lo = 0, prev_lo = 0;
+            // rolled: unrolled, the compiler hoists the 8 x 16 uniform bit masks of all thresholds out of the tile loop and
+            // spills ~270 scalar registers; rolled, a window's masks are a dozen scalar instructions beside its 8 - 17 vector ones
+#pragma unroll 1
+            for (int w = 0; w < ws.W; w++) {
+                const uint32_t lo = (uint32_t)(ws.lo >> (8 * w)) & 0xffu, hi1 = (uint32_t)(ws.hi1 >> (8 * w)) & 0xffu;
+                if (lo != prev_lo) { ge_lo = planes_ge(p, lo); prev_lo = lo; }   // uniform: windows sorted by min share it
+                uint32_t v = ge_lo;
+                if (hi1) v &= ~planes_ge(p, hi1);
+                masks[w * items + q] = v;
+            }
+        }
+        __syncthreads();
+        fetch(tile + gridDim.x);                                         // lands while the tallies below run
+        // phase 2: every wave tallies its (window, 8x8 pair block) slots over the tile's words
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            if (bi[s] < 0) continue;
+            const uint32_t *mi = masks + win[s] * items + bi[s] * BLK * TW, *mj = masks + win[s] * items + bj[s] * BLK * TW;
+#pragma unroll
+            for (int r = 0; r < TW / 64; r++) {
+                uint32_t a[BLK], b[BLK];
+#pragma unroll
+                for (int i = 0; i < BLK; i++) { a[i] = mi[i * TW + r * 64 + lane]; b[i] = mj[i * TW + r * 64 + lane]; }
+#pragma unroll
+                for (int i = 0; i < BLK; i++)
+#pragma unroll
+                    for (int j = 0; j < AJ; j++) {
+                        if (PACK) acc[s][i][j] += (uint32_t)__builtin_popcount(a[i] & b[2 * j]) + ((uint32_t)__builtin_popcount(a[i] & b[2 * j + 1]) << 16);
+                        else acc[s][i][j] += __builtin_popcount(a[i] & b[j]);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+        if (bi[s] < 0) continue;
+        unsigned long long *out = pair + (size_t)((ws.out >> (8 * win[s])) & 0xffu) * N * N;
+#pragma unroll
+        for (int i = 0; i < BLK; i++)
+#pragma unroll
+            for (int j = 0; j < BLK; j++) {
+                const int gi = bi[s] * BLK + i, gj = bj[s] * BLK + j;
+                const uint32_t mine = PACK ? (acc[s][i][j >> 1] >> (16 * (j & 1))) & 0xffffu : acc[s][i][PACK ? 0 : j];
+                const uint32_t v = wave_sum(mine);
+                if (lane == 0 && v && gi < N && gj < N && gi <= gj) atomicAdd(&out[gi * N + gj], (unsigned long long)v);
+            }
+    }
+}
+
+// How many windows one pass of k_gram_mw takes for N tables (0: none -- use one single-window scan per window).
+int gram_windows_per_pass(int N) { return N <= 16 ? 8 : N <= 24 ? 5 : N <= 32 ? 3 : 0; }
+
+// W <= gram_windows_per_pass(N) windows (sorted by min_count: equal neighbours share their comparator); the tallies of
+// window w are ADDED to the N x N block out_index[w] of dev_pair.
+int launch_gram_windows(const uint8_t *const *dev_tables, int N, uint64_t n_slice, const int *min_counts, const int *max_counts,
+                        const int *out_index, int W, unsigned long long *dev_pair, hipStream_t s) {
+    if (N < 1 || W < 1 || W > gram_windows_per_pass(N)) return -1;
+    if (n_slice == 0) return 0;
+    WindowSet ws;
+    ws.W = W;
+    ws.lo = ws.hi1 = ws.out = 0;
+    for (int w = 0; w < W; w++) {
+        ws.lo |= (unsigned long long)(min_counts[w] & 0xff) << (8 * w);
+        ws.hi1 |= (unsigned long long)(max_counts[w] < 255 ? max_counts[w] + 1 : 0) << (8 * w);
+        ws.out |= (unsigned long long)(out_index[w] & 0xff) << (8 * w);
+    }
+    const int NB = (N + BLK - 1) / BLK;
+    const uint64_t n_words = ((n_slice + 2047u) / 2048u) * 64u;
+    const int combos = W * (NB * (NB + 1) / 2);
+    static bool opted = false;
+    if (!opted) {
+        opted = true;
+        hipFuncSetAttribute((const void *)k_gram_mw<1, 128, 2, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipFuncSetAttribute((const void *)k_gram_mw<2, 128, 3, 768>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipFuncSetAttribute((const void *)k_gram_mw<2, 64, 2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    }
+    auto grid_for = [&](int tw, bool pack) {
+        const uint64_t n_tiles = (n_words + tw - 1) / tw;
+        uint64_t grid = n_tiles < 1024u ? n_tiles : 1024u;
+        if (pack) {                                        // 16-bit packed tallies: a lane adds (tw / 64) * 32 per tile at most
+            const uint64_t max_tiles = 65535u / ((uint64_t)(tw / 64) * 32u);
+            if ((n_tiles + grid - 1) / grid > max_tiles) grid = (n_tiles + max_tiles - 1) / max_tiles;
+        }
+        return (uint32_t)grid;
+    };
+    // shapes (threads x loads per thread cover the tile's NBT x TW items; two slots per wave cover W x pair blocks):
+    //   N <= 8    1 pair block  x 8 windows:  8 waves x 1 slot of 64 tallies,           tile of 128 words
+    //   N <= 16   3 pair blocks x 8 windows: 12 waves x 2 slots of 64 packed tallies,  tile of 128 words
+    //   N <= 24   6 pair blocks x 5 windows: 16 waves x 2 slots,                        tile of 64 words
+    //   N <= 32  10 pair blocks x 3 windows: 16 waves x 2 slots,                        tile of 64 words
+    const int NBT = NB * BLK;
+    if (N <= 8) {
+        hipLaunchKernelGGL((k_gram_mw<1, 128, 2, 512>), dim3(grid_for(128, false)), dim3(512), (size_t)W * NBT * 128 * 4, s, dev_tables, N, n_slice, ws, dev_pair);
+    } else if (N <= 16) {
+        if (combos > 24) return -1;
+        hipLaunchKernelGGL((k_gram_mw<2, 128, 3, 768>), dim3(grid_for(128, true)), dim3(768), (size_t)W * NBT * 128 * 4, s, dev_tables, N, n_slice, ws, dev_pair);
+    } else {
+        if (combos > 32) return -1;
+        hipLaunchKernelGGL((k_gram_mw<2, 64, 2, 1024>), dim3(grid_for(64, true)), dim3(1024), (size_t)W * NBT * 64 * 4, s, dev_tables, N, n_slice, ws, dev_pair);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // ------------------------------------------------------------------ launcher --------------------
 int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int min_count, int max_count,
                 unsigned long long *dev_pair, bool zero_first, hipStream_t s) {

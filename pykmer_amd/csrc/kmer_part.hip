@@ -191,9 +191,18 @@ __global__ __launch_bounds__(1024) void k_bases2(uint32_t n_blocks, uint32_t n_f
     uint32_t pre = 0, total = 0;
     for (int j = 0; j < 16; j++) { if (j < w) pre += wsum[j]; total += wsum[j]; }
     if (threadIdx.x < n_blocks) block_tot[threadIdx.x] = pre + inc - v;
+    // the sum of all rooms in 64 bits (the 32-bit scan above wraps silently if it ever passed 2^32; feed_piece keeps
+    // capacity2 below that, so this can only fire on an internal error -- but then it does fire)
+    __shared__ unsigned long long total64;
+    if (threadIdx.x == 0) total64 = 0ull;
+    __syncthreads();
+    unsigned long long mine = v;
+    for (int d = 32; d; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if (lane == 0 && mine) atomicAdd(&total64, mine);
+    __syncthreads();
     if (threadIdx.x == 0) {
         final_start[n_final] = total;
-        if ((uint64_t)total > pl.capacity2) flags[0] = 1u;               // cannot happen with the bounds of make_part_plan; be loud if it does
+        if (total64 > pl.capacity2) flags[0] = 1u;                       // cannot happen with the bounds of make_part_plan; be loud if it does
     }
 }
 __global__ __launch_bounds__(1024) void k_starts2(uint32_t n_final, const uint32_t *__restrict__ block_base, uint32_t *__restrict__ final_start,
@@ -866,8 +875,9 @@ void part_set_attributes() {
     hipFuncSetAttribute((const void *)k_bucket_count_bytes<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, K6_BYTES_LDS);
 }
 
-// tooling (tools/occupancy.py): resident workgroups per CU of the bucket-count kernels as the runtime computes them
-extern "C" int pk_internal_occupancy(int which) {
+// diagnostics (include/pykmer_hip.h; tools/occupancy.py): resident workgroups per CU of the bucket-count / level-2 kernels
+// as the runtime computes them
+extern "C" int pk_diag_occupancy(int which) {
     int n = -1;
     hipError_t e = hipErrorInvalidValue;
     if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)k_bucket_count_half<1024>, 1024, 65536);

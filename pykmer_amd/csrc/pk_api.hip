@@ -349,8 +349,27 @@ static int ensure_recs(pk_indexer *ix, uint64_t need) {
 }
 
 // one feed of at most FEED_MAX bytes: structure pass -> squeeze -> bucket layout -> fused k-mer assembly + level-1
-// sort -> level 2 -> bucket count
-static const uint64_t FEED_MAX = 3ULL << 30;             // keeps every record index (capacity x 9/8) below 2^32
+// sort -> level 2 -> bucket count.  Record positions are 32-bit: both bucket areas (their capacity + the dump tile) must
+// end below 2^32 records.  The worst plan is k = 17 (2^18 final buckets x 4104 records of fixed slack + 25 % on the
+// estimate): 2 GiB of text -> capacity2 = 3.76e9.  feed_piece checks the plan it actually got and refuses otherwise.
+static const uint64_t FEED_MAX = 2ULL << 30;
+
+static bool plan_fits_u32(const PartPlan &pl) {
+    const uint64_t lim = (1ULL << 32) - (16384 + 64);          // the dump tile behind the buckets (part_common.h: TILE)
+    return pl.capacity1 < lim && pl.capacity2 < lim;
+}
+
+// diagnostics (include/pykmer_hip.h): the partition plan of one feed of n_bytes at kmer_len k
+extern "C" int pk_diag_plan(int k, uint64_t n_bytes, uint64_t out[8]) {
+    if (!out) return fail(PK_ERR_ARG, "null output");
+    int rc = check_k(k, k > 17 ? 2 * k - 34 : 0, 0);
+    if (rc) return rc;
+    if (n_bytes == 0) n_bytes = FEED_MAX;
+    const PartPlan pl = make_part_plan((uint32_t)k, n_bytes, k > 17 ? (uint32_t)(2 * k - 34) : 0u, 0u);
+    out[0] = FEED_MAX; out[1] = pl.capacity1; out[2] = pl.capacity2; out[3] = pl.B1; out[4] = pl.B2; out[5] = pl.fb_bits;
+    out[6] = pl.n_chunks; out[7] = plan_fits_u32(pl) ? 1 : 0;
+    return PK_OK;
+}
 
 static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
     const uint32_t n_chunks = (uint32_t)((n_bytes + CHUNK - 1) / CHUNK);
@@ -370,6 +389,7 @@ static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
     if (rc) return rc;
     ix->n_recs = n_recs;
     PartPlan pl = make_part_plan((uint32_t)ix->k, n_bytes, (uint32_t)ix->slice_bits, (uint32_t)ix->slice_index);
+    if (!plan_fits_u32(pl)) return fail(PK_ERR_ARG, "feed of %llu bytes needs record positions beyond 2^32 (internal limit); split it", (unsigned long long)n_bytes);
     PartWorkspace lay;
     const size_t need = part_workspace_bytes(pl, n_bytes, &lay);
     if (need > ix->ws_cap) {
@@ -703,6 +723,51 @@ extern "C" int pk_gram_device_accumulate(const void *const *dev_tables, int N, u
                                          void *dev_pair_accum, int device, double *kernel_seconds_out) {
     if (!dev_pair_accum) return fail(PK_ERR_ARG, "null accumulator");
     return gram_scan_device(dev_tables, N, n_slice, min_count, max_count, nullptr, dev_pair_accum, true, device, kernel_seconds_out);
+}
+
+// Several windows over the same staged slices: one pass per group of windows (k_gram_mw) where the kernel has room for
+// them, one single-window scan each otherwise.  PK_GRAM_MW=0: always one scan per window (comparison runs).
+extern "C" int pk_gram_device_accumulate_windows(const void *const *dev_tables, int N, uint64_t n_slice, const int *min_counts,
+                                                 const int *max_counts, int n_windows, void *dev_pair_accum, int device,
+                                                 double *kernel_seconds_out) {
+    if (!dev_pair_accum) return fail(PK_ERR_ARG, "null accumulator");
+    if (n_windows < 1 || n_windows > 255 || !min_counts || !max_counts) return fail(PK_ERR_ARG, "between 1 and 255 windows per call");
+    int rc = PK_OK;
+    for (int w = 0; w < n_windows; w++)
+        if ((rc = check_counts(N, min_counts[w], max_counts[w]))) return rc;
+    if (!dev_tables) return fail(PK_ERR_ARG, "null table list");
+    for (int i = 0; i < N; i++)
+        if (!dev_tables[i] || ((uintptr_t)dev_tables[i] & 15u)) return fail(PK_ERR_ARG, "table %d: device pointer must be 16-byte aligned", i);
+    static const bool mw_on = !(getenv("PK_GRAM_MW") && atoi(getenv("PK_GRAM_MW")) == 0);
+    const int per_pass = mw_on ? gram_windows_per_pass(N) : 0;
+    HIPCHK(hipSetDevice(device));
+    GramCtx *c = nullptr;
+    if ((rc = gram_ctx(device, &c))) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    unsigned long long *acc = (unsigned long long *)dev_pair_accum;
+    HIPCHK(hipMemcpyAsync(c->d_ptrs, dev_tables, N * sizeof(void *), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->e0, c->stream));
+    std::vector<int> order(n_windows);
+    for (int w = 0; w < n_windows; w++) order[w] = w;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return min_counts[a] < min_counts[b]; });
+    for (int at = 0; at < n_windows;) {
+        const int take = (per_pass >= 2 && n_windows - at >= 2) ? std::min(per_pass, n_windows - at) : 1;
+        int lrc;
+        if (take == 1) {
+            const int w = order[at];
+            lrc = launch_gram(c->d_ptrs, N, n_slice, min_counts[w], max_counts[w], acc + (size_t)w * N * N, false, c->stream);
+        } else {
+            int mn[8], mx[8], out[8];
+            for (int i = 0; i < take; i++) { mn[i] = min_counts[order[at + i]]; mx[i] = max_counts[order[at + i]]; out[i] = order[at + i]; }
+            lrc = launch_gram_windows(c->d_ptrs, N, n_slice, mn, mx, out, take, acc, c->stream);
+        }
+        if (lrc) return fail(PK_ERR_HIP, "gram kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        at += take;
+    }
+    HIPCHK(hipEventRecord(c->e1, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (kernel_seconds_out) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->e0, c->e1)); *kernel_seconds_out = ms * 1e-3; }
+    return PK_OK;
 }
 
 extern "C" int pk_gram(const uint8_t *const *tables, int N, uint64_t n, int min_count, int max_count, uint64_t *matrix_out,

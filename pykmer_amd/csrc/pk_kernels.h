@@ -85,4 +85,11 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
 int launch_gram(const uint8_t *const *dev_tables, int N, uint64_t n_slice, int min_count, int max_count,
                 unsigned long long *dev_pair, bool zero_first, hipStream_t s);
 
+// Several validity windows in one pass over the tables (threshold sweeps): at most gram_windows_per_pass(N) windows
+// per launch (0: this N is served by one launch_gram per window), sorted by min_count; window w's tallies are added to
+// block out_index[w] (< 256) of dev_pair.
+int gram_windows_per_pass(int N);
+int launch_gram_windows(const uint8_t *const *dev_tables, int N, uint64_t n_slice, const int *min_counts, const int *max_counts,
+                        const int *out_index, int W, unsigned long long *dev_pair, hipStream_t s);
+
 }  // namespace pk

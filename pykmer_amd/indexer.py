@@ -59,25 +59,68 @@ def _names_from_stream(input_file: str, records: np.ndarray) -> List[bytes]:
     return names
 
 
+GZ_PIECE = 256 << 20            # compressed inputs: inflated bytes per piece (piece i + 1 inflates while piece i is fed)
+
+
 class _Input:
-    """The decompressed byte stream of a FASTA file, in FEED_BYTES pieces (anything with the buffer protocol), and
+    """The decompressed byte stream of a FASTA file, in pieces (anything with the buffer protocol), and
     afterwards the header texts at given byte ranges of that stream.
 
     A plain file is mapped, not read: the pieces are views of the page cache that the library copies to HBM from
     several threads, and the names are sliced from the mapping.  A BGZF-compressed FASTA (bgzip output) is inflated
-    block-parallel in one go when it is small enough to keep.  Other gzip streams are read through gzip.open like
-    the reference does (indexer.py:112-115); their pieces are kept for the names while they fit RESIDENT_LIMIT,
-    otherwise the stream is inflated a second time."""
+    block-parallel, GZ_PIECE bytes at a time, the next piece while the GPU takes the current one (bgzf.iter_pieces).
+    Other gzip streams are read through gzip.open like the reference does (indexer.py:112-115), by a producer thread
+    that stays one piece ahead of the feed.  Inflated pieces are kept for the names while they fit RESIDENT_LIMIT
+    (`keep`; the later address slices of a sliced count never ask for names), otherwise the stream is inflated a
+    second time for them."""
 
-    def __init__(self, input_file: str):
+    def __init__(self, input_file: str, keep: bool = True, quiet: bool = False):
         self.path = input_file
         self.gz = input_file.endswith((".gz", ".bgz"))
-        self.whole = None                   # BGZF: the inflated stream
-        self.kept, self.kept_bytes = [], 0  # gzip: pieces in order, or None once they no longer fit
+        self.quiet = quiet
+        self.kept, self.kept_bytes = ([] if keep else None), 0   # compressed inputs: pieces in order, or None once they no longer fit
+
+    def _say(self, text: str) -> None:
+        if not self.quiet:
+            print(text)
+
+    def _keep(self, piece) -> None:
+        if self.kept is not None:
+            self.kept.append(piece)
+            self.kept_bytes += len(piece)
+            if self.kept_bytes > RESIDENT_LIMIT:
+                self.kept = None
+
+    def _gzip_pieces(self):
+        """gzip.open read by a producer thread, one piece ahead of the consumer."""
+        import queue
+        import threading
+        q: "queue.Queue" = queue.Queue(maxsize=1)
+
+        def produce():
+            try:
+                with gzip.open(self.path, "rb") as fh:
+                    while True:
+                        piece = fh.read(GZ_PIECE)
+                        q.put(piece)
+                        if not piece:
+                            return
+            except BaseException as exc:                    # handed to the consumer, which raises it
+                q.put(exc)
+        t = threading.Thread(target=produce, daemon=True)
+        t.start()
+        while True:
+            piece = q.get()
+            if isinstance(piece, BaseException):
+                raise piece
+            if not piece:
+                break
+            yield piece
+        t.join()
 
     def pieces(self):
         if not self.gz:
-            print(f"READING FASTA FROM {self.path}")
+            self._say(f"READING FASTA FROM {self.path}")
             if os.path.getsize(self.path) == 0:
                 return
             import mmap
@@ -93,23 +136,15 @@ class _Input:
                 pass
             return
         from . import bgzf
-        if bgzf.is_bgzf(self.path) and os.path.getsize(self.path) * 6 <= RESIDENT_LIMIT:
-            print(f"READING FASTA FROM BGZF {self.path}")
-            self.whole = bgzf.decompress_file(self.path)
-            for off in range(0, self.whole.size, FEED_BYTES):
-                yield self.whole[off:off + FEED_BYTES]
-            return
-        with _open_input(self.path) as fh:
-            while True:
-                piece = fh.read(FEED_BYTES)
-                if not piece:
-                    return
-                if self.kept is not None:
-                    self.kept.append(piece)
-                    self.kept_bytes += len(piece)
-                    if self.kept_bytes > RESIDENT_LIMIT:
-                        self.kept = None
-                yield piece
+        if bgzf.is_bgzf(self.path):
+            self._say(f"READING FASTA FROM BGZF {self.path}")
+            source = bgzf.iter_pieces(self.path, GZ_PIECE)
+        else:
+            self._say(f"READING FASTA FROM PYGZ {self.path}")
+            source = self._gzip_pieces()
+        for piece in source:
+            self._keep(piece)
+            yield piece
 
     def names(self, records: np.ndarray) -> List[bytes]:
         spans = [(int(r["name_off"]), int(r["name_len"])) for r in records]
@@ -119,11 +154,18 @@ class _Input:
             import mmap
             with open(self.path, "rb") as fh, mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ) as mm:
                 return [mm[off:off + ln] for off, ln in spans]
-        if self.whole is not None:
-            return [self.whole[off:off + ln].tobytes() for off, ln in spans]
         if self.kept is not None:
-            blob = self.kept[0] if len(self.kept) == 1 else b"".join(self.kept)
-            return [blob[off:off + ln] for off, ln in spans]
+            # header texts out of the kept pieces: a name may straddle two of them
+            starts = np.cumsum([0] + [len(p) for p in self.kept])
+            out = []
+            for off, ln in spans:
+                i = int(np.searchsorted(starts, off, side="right")) - 1
+                got = bytes(memoryview(self.kept[i])[off - starts[i]: off - starts[i] + ln])
+                while len(got) < ln and i + 1 < len(self.kept):
+                    i += 1
+                    got += bytes(memoryview(self.kept[i])[: ln - len(got)])
+                out.append(got)
+            return out
         return _names_from_stream(self.path, records)
 
 
@@ -176,15 +218,12 @@ def count_file(input_file: str, kmer_len: int, device: int = 0, table_file: str 
     def count_slice(s: int):
         """Counts slice s and copies it into table[s * size : (s + 1) * size]; the first slice's pieces feed the hasher
         as they land, later slices are hashed whole once it is their turn (the file is hashed in address order)."""
-        src = source if s == 0 else _Input(input_file)
+        src = source if s == 0 else _Input(input_file, keep=False, quiet=True)   # only slice 0's names and messages are used
         _mark("creating the indexer (library load, HIP start-up, table and workspace allocation)")
         with _lib.Indexer(kmer_len, device=devices[s % len(devices)], slice_index=s, n_slices=n_slices) as ix:
-            import contextlib
-            import io
             _mark("indexer ready")
-            with contextlib.redirect_stdout(io.StringIO()) if s else contextlib.nullcontext():
-                for piece in src.pieces():
-                    ix.feed(piece)
+            for piece in src.pieces():
+                ix.feed(piece)
             fin = ix.finish()
             _mark("text counted")
             fin["records"] = ix.records(fin["n_records"]) if s == 0 else None

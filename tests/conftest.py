@@ -9,8 +9,15 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# Switches that select an alternate library or kernel (experiments: tools/build_variant.sh): a test run must
+# measure and check the product as shipped, so they have to be unset.
+EXPERIMENT_SWITCHES = ("PK_LIB", "PK_K15", "PK_K6_BYTES", "PK_GRAM_MW", "PK_DENSE_SHIFT", "PK_WG1", "PK_GRID2", "PK_XCD", "PK_SPARSE_MAX")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    set_ = [v for v in EXPERIMENT_SWITCHES if v in os.environ]
+    assert not set_, f"experiment switches set in the environment: {set_} -- the tests check the library as shipped"
     # The shared library is a build artefact (git-ignored): on a fresh checkout build it once, the way
     # __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU).  If hipcc is absent the
     # tests that need the library fail loudly with the ImportError from pykmer_amd._lib.load().

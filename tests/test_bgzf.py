@@ -144,3 +144,37 @@ def test_gzi_and_bgz_as_the_reference_reads_them(tmp_path, manifest):
         assert lines == want
         assert hashlib.sha256(open(dst, "rb").read()).hexdigest() == case["bgz_sha256"]
         assert hashlib.sha256(open(gzi, "rb").read()).hexdigest() == case["gzi_sha256"]
+
+
+def test_block_index_and_pieces(tmp_path, monkeypatch):
+    """The block index (from the .gzi, or from one walk over the headers; cached) behind decompress_range, and the
+    piecewise inflate the indexer feeds a bgzipped FASTA with (indexer.py:112-115 streams gzip.open)."""
+    monkeypatch.setattr(bgzf, "BLOCK_INPUT", 4096)
+    src = tmp_path / "t.bin"
+    data = _table(1_000_003, 11)
+    data.tofile(src)
+    dst, gzi = bgzf.compress_file(str(src), threads=2)
+    c_offs, c_sizes, u_offs = bgzf.block_index(dst)
+    assert len(c_offs) == len(c_sizes) == len(u_offs) - 1 == -(-data.size // 4096)
+    assert int(u_offs[-1]) == data.size and int(c_offs[0]) == 0 and (np.diff(c_offs) == c_sizes[:-1]).all()
+    assert bgzf.block_index(dst) is bgzf.block_index(dst)                                   # cached
+    os.remove(gzi)
+    bgzf._INDEX_CACHE.clear()
+    again = bgzf.block_index(dst)                                                            # the same index from the headers alone
+    assert all(np.array_equal(a, b) for a, b in zip(again, (c_offs, c_sizes, u_offs)))
+    rng = np.random.default_rng(3)
+    for _ in range(30):
+        lo = int(rng.integers(0, data.size))
+        hi = int(rng.integers(lo, min(data.size, lo + 50_000) + 1))
+        part, inflated = bgzf.decompress_range(dst, lo, hi)
+        assert np.array_equal(part, data[lo:hi]) and inflated <= (hi - lo) + 2 * 4096
+    for piece in (1, 4096, 10_000, 1 << 20, 1 << 30):
+        parts = list(bgzf.iter_pieces(dst, piece, threads=3))
+        assert np.array_equal(np.concatenate(parts), data)
+        assert all(p.size % 4096 == 0 for p in parts[:-1])                                   # whole blocks
+        if piece >= 4096:
+            assert all(p.size <= piece for p in parts)
+    empty = tmp_path / "e.bin"
+    empty.write_bytes(b"")
+    dst0, _ = bgzf.compress_file(str(empty))
+    assert list(bgzf.iter_pieces(dst0, 100)) == []

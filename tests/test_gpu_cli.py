@@ -100,3 +100,73 @@ def test_indexer_cli_counts_in_address_slices(gpu, tmp_path, manifest):
         meta = json.load(fh)
     for f, v in case["expect"].items():
         assert meta[f] == v, f
+
+
+def _family_kins(tmp_path, manifest, tag="G7_k7_n13_default"):
+    case = manifest["merger"][tag]
+    kins = []
+    for i, spec in enumerate(case["inputs"]):
+        fa = tmp_path / f"s{i:02d}.fa"
+        fa.write_bytes(inputs.make_input(spec))
+        _run(os.path.join(ROOT, "indexer.py"), str(fa), f"s{i}", "7", cwd=str(tmp_path))
+        kins.append(f"{fa}.07.kin")
+    return kins
+
+
+def test_merger_cli_one_process_per_gpu(gpu, tmp_path, manifest):
+    """merger.py:213-239 with the reference's pool (merger.py:137-178) replaced by ranks: `--gpus 2` starts two ranks (here both
+    on the one GPU, so the rehearsal backend gloo: RCCL refuses two ranks on one device), each scans its half of the k-mer
+    address range, one all-reduce sums the partials, rank 0 writes.  Then the RCCL form of the same entry: a launcher's
+    environment (WORLD_SIZE=1, as torchrun sets it) makes the CLI join an nccl group."""
+    kins = _family_kins(tmp_path, manifest)
+    want = np.array(manifest["merger"]["G7_k7_n13_min2"]["matrix"], dtype=np.uint64)
+    env = dict(os.environ, PK_DIST_BACKEND="gloo")
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(v, None)
+    proj = str(tmp_path / "two")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "merger.py"), proj, *kins, "--min-count", "2", "--gpus", "2"], cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert np.array_equal(np.load(proj + ".002-255.kma")["matrix"], want)
+    assert r.stdout.count("saving") == 2                                             # rank 0 alone prints and writes
+    with open(proj + ".002-255.kma.json") as fh:
+        assert [os.path.basename(d["index_file"]) for d in json.load(fh)["data"]] == manifest["merger"]["G7_k7_n13_min2"]["order"]
+    # RCCL: one rank, joined through the launcher's environment
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
+    env.pop("PK_DIST_BACKEND", None)
+    proj = str(tmp_path / "one")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "merger.py"), proj, *kins, "--sweep", "2-255,1-3"], cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert np.array_equal(np.load(proj + ".002-255.kma")["matrix"], want)
+    assert np.array_equal(np.load(proj + ".001-003.kma")["matrix"], np.array(manifest["merger"]["G7_k7_n13_max3"]["matrix"], dtype=np.uint64))
+
+
+@pytest.mark.parametrize("piece", [0, 3000])
+def test_indexer_cli_on_bgzipped_fasta(gpu, tmp_path, manifest, small_tables, piece, monkeypatch):
+    """indexer.py:112-115 opens .gz / .bgz inputs through gzip.open; here a BGZF FASTA (what `bgzip` writes) is inflated
+    block-parallel in pieces that are fed while the next one inflates.  The reference's golden for the gzipped edge FASTA
+    (G3_edge_gz_k7) must come out, also with pieces so small that headers, records and k-mers straddle them."""
+    from pykmer_amd import bgzf, indexer
+    case = manifest["indexer"]["G3_edge_gz_k7"]
+    data = inputs.make_input(case["input"])
+    plain = tmp_path / "edge.fa"
+    plain.write_bytes(gzip.decompress(data) if data[:2] == b"\x1f\x8b" else data)
+    fa = tmp_path / case["input_file"]
+    if piece:
+        monkeypatch.setattr(bgzf, "BLOCK_INPUT", 1000)                               # small blocks, so that pieces of 3 blocks exist
+    bgzf.compress_file(str(plain), str(fa), index=False)
+    assert bgzf.is_bgzf(str(fa)) and str(fa).endswith(".gz")
+    if piece:
+        assert len(list(bgzf.iter_pieces(str(fa), piece))) > 10
+        monkeypatch.setattr(indexer, "GZ_PIECE", piece)
+        indexer.main([str(fa), "sample", "7"])
+    else:
+        _run(os.path.join(ROOT, "indexer.py"), str(fa), "sample", "7", cwd=str(tmp_path))
+    kin = f"{fa}.07.kin"
+    with open(kin + ".json") as fh:
+        meta = json.load(fh)
+    for f, v in case["expect"].items():
+        if f not in ("input_file_cheksum", "input_file_size"):                       # the compressed bytes differ from python-gzip's
+            assert meta[f] == v, f
+    assert np.array_equal(np.fromfile(kin, dtype=np.uint8), small_tables["G3_edge_gz_k7"])

@@ -80,6 +80,34 @@ def test_golden_k17(gpu, manifest):
     _expect_fields(gpu.count_fasta(data, 17), data, case)
 
 
+def test_full_config4_k17(gpu):
+    """config 4 at full size: the ~800 Mbp C2 genome at k = 17 (16 GiB table in HBM), the whole table byte for byte against
+    the oracle's, with the byte-counter wrap -> recount path (k_bucket_count_bytes) known to have run.  The oracle here
+    is the all-cores twin (pinned to the scalar one in tests/test_oracle_golden.py), the scalar one if it declines."""
+    import os
+    data = inputs.make_input({"gen": "c2"})
+    k = 17
+    want = oracle.count_fasta_mt(data, k, len(os.sched_getaffinity(0))) or oracle.count_fasta(data, k)
+    with gpu.Indexer(k) as ix:
+        ix.feed(data)
+        fin = ix.finish()
+        t = ix.timings()
+        assert t["buckets_recounted"] > 0, "no bucket took the wrap -> recount path: the test no longer covers it"
+        assert fin["num_kmers"] == want["num_kmers"] and fin["total_bp"] == want["total_bp"] == 800_000_000
+        wt = want["table"]
+        hist = np.zeros(256, dtype=np.uint64)
+        step = 1 << 30
+        got = np.empty(step, dtype=np.uint8)
+        for off in range(0, 4 ** k, step):                                # 16 slices of 1 GiB: compare, tally, move on
+            ix.table_slice_to_host(got, off)
+            assert np.array_equal(got, wt[off:off + step]), f"table differs in [{off}, {off + step})"
+            hist += np.bincount(got, minlength=256).astype(np.uint64)
+        assert np.array_equal(fin["hist256"], hist)                       # Header.update_stats input (tools.py:246-263)
+        assert int(hist[255]) > 0 and int(wt[0]) == 255                   # saturated addresses exist (indexer.py:239,262)
+        print(f"k=17 full size: {t['buckets_recounted']} buckets recounted, {t['relayouts']} relayouts, "
+              f"{int(hist[1:].sum())} distinct k-mers")
+
+
 def test_full_config2_k15(gpu, manifest):
     """config 2: the ~800 Mbp synthetic genome at k=15, bit-exact against the reference's own run when
     that golden exists (G6, ~1 h of reference time), and through size-independent properties always."""

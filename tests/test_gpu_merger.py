@@ -196,3 +196,159 @@ def test_merge_host_path_sub_slices_and_threads(gpu, tmp_path, monkeypatch):
     raw = [h.bytes_delivered for i, h in enumerate(headers) if i != 2]
     assert all(b == 4 ** k for b in raw)                                # every byte of a raw table exactly once
     assert headers[2].bytes_delivered <= 4 ** k + 2 * len(merger._sub_slices(0, 4 ** k // 2, N, 0)) * bgzf.BLOCK_INPUT
+
+
+# ------------------------------------------------------------------ several windows in one pass ------------
+SWEEP9 = [(1, 255), (2, 255), (1, 3), (2, 5), (128, 255), (100, 200), (1, 127), (129, 254), (255, 255)]
+
+
+def _accumulate_windows(gpu, tables, windows):
+    """Host tables -> device buffers -> ONE pk_gram_device_accumulate_windows call -> W x N x N."""
+    N, n = len(tables), tables[0].size
+    bufs = [gpu.DeviceBuffer(n, 0) for _ in range(N)]
+    acc = gpu.DeviceBuffer(len(windows) * N * N * 8, 0)
+    try:
+        for b, t in zip(bufs, tables):
+            b.upload(t)
+        acc.zero()
+        gpu.gram_device_accumulate_windows([b.ptr for b in bufs], n, acc.ptr, windows)
+        return acc.download().view(np.uint64).reshape(len(windows), N, N)
+    finally:
+        for b in bufs + [acc]:
+            b.free()
+
+
+@pytest.mark.parametrize("N", [2, 5, 8, 9, 13, 16, 17, 24, 25, 32, 33, 49])
+def test_window_sweep_in_one_pass_vs_oracle(gpu, N):
+    """Every window of a sweep from one call (k_gram_mw: bit planes + ripple comparators; N > 32: one scan per window)
+    against the oracle's pair loop (tools.py:473-482), for window lists that do and do not fill a pass, sorted and not."""
+    rng = np.random.default_rng(300 + N)
+    for n in (4 ** 7, 300_001):
+        tables = _random_tables(rng, N, n)
+        for windows in (SWEEP9, SWEEP9[:2], [(5, 9)], [(7, 255), (1, 255), (3, 255), (3, 20), (2, 255), (1, 1)]):
+            got = _accumulate_windows(gpu, tables, windows)
+            for w, (mn, mx) in enumerate(windows):
+                assert np.array_equal(gpu.gram_expand(got[w]), oracle.gram(tables, mn, mx)), (N, n, mn, mx)
+        if N > 9:
+            break                                                       # the ragged size once per kernel shape is enough
+
+
+def test_window_sweep_accumulates_and_rejects(gpu):
+    rng = np.random.default_rng(5)
+    tables = _random_tables(rng, 4, 4 ** 6)
+    N, n = 4, tables[0].size
+    bufs = [gpu.DeviceBuffer(n, 0) for _ in range(N)]
+    acc = gpu.DeviceBuffer(2 * N * N * 8, 0)
+    for b, t in zip(bufs, tables):
+        b.upload(t)
+    acc.zero()
+    half = (n // 2) & ~31
+    wins = [(1, 255), (2, 4)]
+    gpu.gram_device_accumulate_windows([b.ptr for b in bufs], half, acc.ptr, wins)                     # two address sub-slices add up
+    gpu.gram_device_accumulate_windows([b.ptr + half for b in bufs], n - half, acc.ptr, wins)
+    got = acc.download().view(np.uint64).reshape(2, N, N)
+    for w, (mn, mx) in enumerate(wins):
+        assert np.array_equal(gpu.gram_expand(got[w]), oracle.gram(tables, mn, mx))
+    for bad in ([(0, 255)], [(1, 256)], []):                            # merger.py:90-91
+        with pytest.raises(ValueError):
+            gpu.gram_device_accumulate_windows([b.ptr for b in bufs], n, acc.ptr, bad)
+
+
+@pytest.mark.parametrize("N", [13, 32])
+def test_window_sweep_full_size(gpu, N):
+    """Eight thresholds over N tables of 4^15 bytes from one staging: every total and a spread of shared tallies against
+    torch; the time of the sweep is printed beside the time of ONE single-window scan."""
+    import torch
+    torch.cuda.empty_cache()
+    n = 4 ** 15
+    tabs = _torch_tables(n, N, seed=70 + N)
+    ptrs = [t.data_ptr() for t in tabs]
+    windows = [(1, 255), (2, 255), (3, 255), (4, 255), (5, 200), (8, 255), (1, 50), (2, 20)]
+    acc = torch.zeros((len(windows), N, N), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    secs = gpu.gram_device_accumulate_windows(ptrs, n, acc.data_ptr(), windows)
+    acc.zero_()
+    torch.cuda.synchronize()
+    secs = gpu.gram_device_accumulate_windows(ptrs, n, acc.data_ptr(), windows)
+    _, one = gpu.gram_device_partial(ptrs, n, 1, 255)
+    got = acc.cpu().numpy()
+    for w, (mn, mx) in enumerate(windows):
+        valid = [(t >= mn) & (t <= mx) for t in tabs]
+        for i in range(N):
+            assert int(got[w, i, i]) == int(valid[i].sum().item()), (N, mn, mx, i)
+        for i, j in ((0, 1), (2, N - 1), (N // 2, N // 2 + 1), (N - 2, N - 1)):
+            assert int(got[w, i, j]) == int((valid[i] & valid[j]).sum().item()), (N, mn, mx, i, j)
+        del valid
+    print(f"sweep of {len(windows)} windows, N={N} k=15: {secs * 1e3:.2f} ms = {secs / one:.2f} x one scan ({one * 1e3:.2f} ms)")
+    del tabs
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------ the RCCL branch of the product merge -----------------
+def test_merge_through_rccl_group_of_one(gpu, tmp_path, manifest):
+    """merger.merge(group=True) with torch.distributed on backend nccl (= RCCL), world_size 1: the branch a multi-GPU merge
+    takes on every rank -- accumulator allocated by torch in HBM, pk_gram_device_accumulate_windows adds into it through
+    acc_ptr, dist.all_reduce sums it -- on real files, against the reference's matrices and against the single-process path."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from pykmer_amd import merger
+    from test_host_layer import _family_indexes
+    paths = sorted(_family_indexes(tmp_path, manifest))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl"
+        seen = []
+        real = merger.gpu_partial
+
+        def spy(*a, **kw):
+            seen.append(kw.get("acc_ptr"))
+            return real(*a, **kw)
+        merger.gpu_partial = spy
+        try:
+            wins = [(1, 255), (2, 255), (1, 3), (2, 5)]
+            _, first = merger.merge(str(tmp_path / "rccl"), paths, group=True, windows=wins)
+        finally:
+            merger.gpu_partial = real
+        assert len(seen) == 1 and seen[0], "the merge did not hand the kernel an accumulator in HBM (acc_ptr)"
+    finally:
+        dist.destroy_process_group()
+    _, plain = merger.merge(str(tmp_path / "plain"), paths, windows=wins)
+    assert np.array_equal(first, plain)
+    for (mn, mx), tag in zip(wins, ("default", "min2", "max3", "min2max5")):
+        want = np.array(manifest["merger"][f"G7_k7_n13_{tag}"]["matrix"], dtype=np.uint64)
+        assert np.array_equal(np.load(tmp_path / f"rccl.{mn:03d}-{mx:03d}.kma")["matrix"], want), tag
+        assert np.array_equal(np.load(tmp_path / f"plain.{mn:03d}-{mx:03d}.kma")["matrix"], want), tag
+
+
+def test_merge_of_resident_tables(gpu):
+    """merger.ResidentTable: tables that never left HBM (what bench.py merges) go through the same pair_matrix."""
+    import synth
+    from pykmer_amd import merger
+    k, N = 9, 6
+    n = 4 ** k
+    host, bufs = [], []
+    for i in range(N):
+        fa, _ = synth.family(i, 50_000)
+        host.append(gpu.count_fasta(fa, k)["table"])
+        b = gpu.DeviceBuffer(n, 0)
+        b.upload(host[-1])
+        bufs.append(b)
+    tabs = [merger.ResidentTable(b.ptr, n, n, device=0) for b in bufs]
+    stats = {}
+    got = merger.pair_matrix(tabs, [(1, 255), (2, 7)], devices=(0,), stats=stats)
+    assert stats["kernel_seconds"] > 0
+    for pair, (mn, mx) in zip(got, ((1, 255), (2, 7))):
+        assert np.array_equal(gpu.gram_expand(pair), oracle.gram(host, mn, mx))
+    # an address slice held on its own (a rank's share): the resident part starts at `first`
+    lo, hi = merger.address_slice(n, 1, 3)
+    part = [merger.ResidentTable(b.ptr + lo, hi - lo, n, device=0, first=lo) for b in bufs]
+    sl = merger.gpu_partial(part, lo, hi, [(1, 255)], 0, 1)
+    assert np.array_equal(gpu.gram_expand(sl[0]), oracle.gram([t[lo:hi] for t in host], 1, 255))
+    for b in bufs:
+        b.free()

@@ -25,14 +25,35 @@ def _declared_symbols():
     return sorted(set(re.findall(r"\b(pk_[a-z0-9_]+)\s*\(", text)))
 
 
-def test_library_exports_every_declared_symbol():
+def _exported_symbols():
+    """The dynamic symbol table of the built library (nm -D): every defined pk_* function."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    return sorted({line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("pk_") and line.split()[-2] in "TW"})
+
+
+def test_library_exports_exactly_the_declared_symbols():
     lib = _lib.load()                                   # raises if the .so was not built
     declared = _declared_symbols()
     assert len(declared) >= 20
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/pykmer_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == declared, "ctypes signatures out of sync with the header"
-    assert lib.pk_version() == 2
+    assert _exported_symbols() == declared, "the library exports a pk_* symbol that include/pykmer_hip.h does not declare (or the reverse)"
+    assert lib.pk_version() == 3
+
+
+def test_feed_pieces_keep_record_positions_in_32_bits():
+    """Record positions inside one feed piece are 32-bit (bucket starts, cursors, limits): the largest piece the library
+    cuts a feed into must leave both bucket areas + the dump tile below 2^32 for every k -- k = 17 with its 2^18 final
+    buckets of fixed slack is the tight one -- and a plan that does not fit is refused, not wrapped."""
+    feed_max = _lib.diag_plan(15)["feed_max"]
+    assert feed_max % 16 == 0
+    for k in (3, 9, 13, 15, 17, 19, 21):
+        pl = _lib.diag_plan(k)                          # n_bytes = 0: the largest piece
+        assert pl["fits_u32"] == 1, (k, pl)
+        assert max(pl["capacity1"], pl["capacity2"]) + 16384 + 64 < 2 ** 32, (k, pl)
+    assert _lib.diag_plan(17, 3 << 30)["fits_u32"] == 0                            # the old 3 GiB piece did not fit at k = 17
 
 
 def test_numpy_free_loader_serves_the_same_library():
@@ -278,6 +299,62 @@ def test_merge_validation(tmp_path, manifest):
         merger.main(["proj", paths[0]])                                              # argparse: Kmer_N needs one more (merger.py:53-54)
     args = merger.build_parser().parse_args(["p", "a.kin", "b.kin", "--min-count", "3", "--threads", "2"])
     assert args.min_count == 3 and args.max_count == 255 and args.block_size == 100_000_000 and args.threads == 2
+
+
+def _cli_rank(rank, world, port, workdir, argv):
+    """One rank of `merger.py` under a launcher's environment, scans stood in for by the oracle (no GPU in this suite)."""
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      PK_DIST_BACKEND="gloo")
+    from pykmer_amd import merger as m
+    import test_host_layer as here
+    m.gpu_partial = here._oracle_partial                  # the default partial_fn is looked up when pair_matrix runs
+    import contextlib
+    import io
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        m.main(argv)
+    with open(os.path.join(workdir, f"stdout_rank{rank}.txt"), "w") as fh:
+        fh.write(out.getvalue())
+
+
+def test_cli_joins_the_process_group_of_its_launcher(tmp_path, manifest):
+    """merger.main under WORLD_SIZE / RANK (what torchrun or `--gpus N` set): every rank validates and scans its address
+    slice, one all-reduce (gloo here, RCCL on GPUs) sums the partials, rank 0 alone prints and writes both windows."""
+    import socket
+    import torch.multiprocessing as mp
+    paths = sorted(_family_indexes(tmp_path, manifest))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    proj = str(tmp_path / "cli")
+    argv = [proj] + list(reversed(paths)) + ["--sweep", "2-255,1-3", "--threads", "2"]
+    mp.spawn(_cli_rank, args=(2, port, str(tmp_path), argv), nprocs=2, join=True)
+    for (mn, mx), tag in (((2, 255), "min2"), ((1, 3), "max3")):
+        want = np.array(manifest["merger"][f"G7_k7_n13_{tag}"]["matrix"], dtype=np.uint64)
+        assert np.array_equal(np.load(f"{proj}.{mn:03d}-{mx:03d}.kma")["matrix"], want), tag
+    out0, out1 = ((tmp_path / f"stdout_rank{r}.txt").read_text() for r in (0, 1))
+    assert out0.count("saving") == 4 and "verifying" in out0 and out1 == ""
+
+
+def test_cli_spawn_ranks_relays_failures(tmp_path, monkeypatch):
+    """`--gpus N` outside a launcher: N child processes with RANK / WORLD_SIZE / MASTER_* set, the parent's exit code is
+    the worst of theirs (exercised with a stand-in script: no GPU here)."""
+    import sys
+    script = tmp_path / "fake_rank.py"
+    script.write_text("import os, sys\n"
+                      "open(os.path.join(os.path.dirname(__file__), 'seen_' + os.environ['RANK']), 'w').write(' '.join(["
+                      "os.environ['WORLD_SIZE'], os.environ['LOCAL_RANK'], os.environ['MASTER_ADDR']] + sys.argv[1:]))\n"
+                      "sys.exit(3 if os.environ['RANK'] == '1' and 'fail' in sys.argv else 0)\n")
+    monkeypatch.setattr(sys, "argv", [str(script)])
+    assert merger.spawn_ranks(3, ["a", "b"]) == 0
+    assert sorted(p.name for p in tmp_path.glob("seen_*")) == ["seen_0", "seen_1", "seen_2"]
+    assert (tmp_path / "seen_2").read_text() == "3 2 127.0.0.1 a b"
+    assert merger.spawn_ranks(2, ["fail"]) == 3
 
 
 def test_address_slices_cover_range():

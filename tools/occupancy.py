@@ -5,4 +5,4 @@ from pykmer_amd import _lib
 lib = _lib.load()
 _lib.device_count()
 for i, name in enumerate(["k_bucket_count_half", "k_bucket_count_bytes", "k_bucket_count_half_lean", "k_scatter2<claim>"]):
-    print(name, lib.pk_internal_occupancy(i))
+    print(name, lib.pk_diag_occupancy(i))
