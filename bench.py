@@ -3,8 +3,11 @@
 genome (BASELINE.json configs[1]), one genome per GPU (weak scaling), plus the
 N=13 k=15 merge scan as a secondary figure.
 
-A step = one whole indexing job on HBM-resident input: zero the 4^15 table, structure scans, the
-fused extract+count kernel, clamp+histogram.  Prints ONE JSON line on rank 0.
+A step = one whole indexing job on HBM-resident input: reset, structure pass (line / record state of every 64-byte
+piece, bases classified once), squeeze (packed 2-bit stream), bucket layout from a sample, fused k-mer assembly +
+level-1 sort (k_walk_sort), level-2 sort, bucket count into the 4^k table (which also keeps the value histogram),
+side list.  Prints ONE JSON line on rank 0.  The merge legs call pykmer_amd.merger.pair_matrix, the function
+merger.py runs.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--bp 800000000] [--no-merge] [--no-cpu]
 """
@@ -139,7 +142,8 @@ def main():
     # the bench measures the library as shipped: no alternate build, no kernel switches (experiments: tools/)
     switches = [v for v in ("PK_LIB", "PK_K15", "PK_K6_BYTES", "PK_GRAM_MW", "PK_DENSE_SHIFT", "PK_WG1", "PK_GRID2", "PK_XCD", "PK_SPARSE_MAX")
                 if v in os.environ]
-    assert not switches, f"experiment switches set in the environment: {switches}"
+    # (kernel experiments, tools/bench_variants.sh: PK_EXPERIMENT=1 lets them through and the JSON line says so)
+    assert not switches or os.environ.get("PK_EXPERIMENT") == "1", f"experiment switches set in the environment: {switches}"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -257,6 +261,8 @@ def main():
                      "bucket_relayouts": relayouts, "buckets_recounted_per_step": recounted},
         "t_kernel_s": elapsed / args.steps,
     }
+    if switches:
+        out["experiment_switches"] = {v: os.environ[v] for v in switches}
 
     # ---- secondary: N x N merge scan over N tables resident in HBM, address range sharded over ranks
     # (N=13: BASELINE configs[2]; N=32: configs[4], the LDS-tiled kernel).  Not part of `value`.

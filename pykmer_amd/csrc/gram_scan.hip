@@ -245,9 +245,9 @@ __global__ __launch_bounds__(MAXT) void k_gram_mw(const uint8_t *const *__restri
         const bool on = c < ws.W * n_pb;
         int a = 0, rem = c % n_pb;
         while (rem >= NB - a) { rem -= NB - a; a++; }
-        win[s] = on ? c / n_pb : -1;
-        bi[s] = on ? a : -1;
-        bj[s] = on ? a + rem : -1;
+        win[s] = __builtin_amdgcn_readfirstlane(on ? c / n_pb : -1);     // wave-uniform: in scalar registers
+        bi[s] = __builtin_amdgcn_readfirstlane(on ? a : -1);
+        bj[s] = __builtin_amdgcn_readfirstlane(on ? a + rem : -1);
     }
     constexpr int AJ = PACK ? BLK / 2 : BLK;
     uint32_t acc[SLOTS][BLK][AJ];
@@ -295,23 +295,34 @@ __global__ __launch_bounds__(MAXT) void k_gram_mw(const uint8_t *const *__restri
         }
         __syncthreads();
         fetch(tile + gridDim.x);                                         // lands while the tallies below run
-        // phase 2: every wave tallies its (window, 8x8 pair block) slots over the tile's words
+        // phase 2: every wave tallies its (window, 8x8 pair block) slots over the tile's words.  Only pairs that exist are
+        // tallied: rows / columns past the last table and, in a diagonal block, the lower triangle are skipped by uniform
+        // branches (N = 13: 91 of the 192 pair slots of its three blocks) -- this phase is vector-issue bound.
 #pragma unroll
         for (int s = 0; s < SLOTS; s++) {
             if (bi[s] < 0) continue;
             const uint32_t *mi = masks + win[s] * items + bi[s] * BLK * TW, *mj = masks + win[s] * items + bj[s] * BLK * TW;
+            const int ni = min(BLK, N - bi[s] * BLK), nj = min(BLK, N - bj[s] * BLK);
+            const bool diag = bi[s] == bj[s];
 #pragma unroll
             for (int r = 0; r < TW / 64; r++) {
                 uint32_t a[BLK], b[BLK];
 #pragma unroll
                 for (int i = 0; i < BLK; i++) { a[i] = mi[i * TW + r * 64 + lane]; b[i] = mj[i * TW + r * 64 + lane]; }
 #pragma unroll
-                for (int i = 0; i < BLK; i++)
+                for (int i = 0; i < BLK; i++) {
+                    if (i >= ni) continue;
 #pragma unroll
                     for (int j = 0; j < AJ; j++) {
-                        if (PACK) acc[s][i][j] += (uint32_t)__builtin_popcount(a[i] & b[2 * j]) + ((uint32_t)__builtin_popcount(a[i] & b[2 * j + 1]) << 16);
-                        else acc[s][i][j] += __builtin_popcount(a[i] & b[j]);
+                        if (PACK) {
+                            if (2 * j >= nj || (diag && 2 * j + 1 < i)) continue;
+                            acc[s][i][j] += (uint32_t)__builtin_popcount(a[i] & b[2 * j]) + ((uint32_t)__builtin_popcount(a[i] & b[2 * j + 1]) << 16);
+                        } else {
+                            if (j >= nj || (diag && j < i)) continue;
+                            acc[s][i][j] += __builtin_popcount(a[i] & b[j]);
+                        }
                     }
+                }
             }
         }
         __syncthreads();

@@ -12,8 +12,9 @@
 // Per base:  fwd = sum 4^(k-1-p) b_p   one v_alignbit on the pair-reversed dwords       (indexer.py:149)
 //            rev = sum 4^p (3 - b_p)   one 64-bit shift of the complemented dwords       (indexer.py:150)
 //            window valid iff no restart bit among the k-1 bases behind its first        (indexer.py:144)
-// The per-lane three-entry cache of recent k-mers (part_common.h, hot keys) keeps tandem repeats out of the
-// record stream as before.
+// Tandem repeats (k-mers equal to the one 1, 2 or 3 bases earlier) are recognised on the packed words themselves
+// (periodicity masks, see the walk loop) and tallied in the per-workgroup hot-key table of part_common.h instead of
+// being emitted as records.
 //
 // Shape: k <= 15 runs 512 threads x 32 bases with 72 KiB of LDS, so TWO workgroups share a CU and one's
 // k-mer assembly (vector ALU) overlaps the other's ranking / parking / run writes (LDS, HBM) -- with one
@@ -21,9 +22,11 @@
 // (64-bit k-mers, digit kept beside the record: 104 KiB) stays at 1024 x 16, one workgroup per CU.
 //
 // Where the runs go: bucket sizes are not known before the k-mers exist.  A sampling launch of the same
-// kernel (COUNT: every 16th slot, tally only) estimates the size of every FINAL bucket (top b1+b2 address
-// bits, <= 2^15 of them; k = 17: of every level-1 bucket), k_provision lays the buckets of both levels out
-// with 12.5 % + a constant of slack each, and the sorts claim room for every run from per-bucket cursors.
+// kernel (COUNT, tally only: one wave's stretch of bases out of every 16 -- every second slot contributes an eighth of
+// itself) estimates the size of every FINAL bucket (top b1+b2 address bits, <= 2^15 of them; k = 17: of every
+// level-1 bucket, the final ones are then sized from a sample of the level-1 records, kmer_part.hip: k_sample2),
+// k_provision lays the buckets of both levels out with 12.5 % + a constant of slack each (k_rooms2: 25 %), and the
+// sorts claim room for every run from per-bucket cursors.
 // A bucket that outgrows its room raises a flag (its runs go to a dump area, nothing is overwritten); every
 // later kernel of the feed then returns at once and the host repeats from here with stride 1, i.e. with
 // exact sizes.  Inputs below 1024 chunks are counted exactly straight away.
@@ -79,9 +82,12 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
     // k as a literal pays (k = 15: 1.39 -> 1.33 ms, k = 17: 2.25 -> 2.03); the digit position as a literal on top of it
     // pays for the 64-bit kernel only (k = 15: 1.33 -> 1.37 with it)
     // (the same literals in the level-2 kernel change nothing: 1.213 ms either way)
-    const uint32_t B = KC == 17 ? 512u : pl.B1, shift = KC == 17 ? 25u : pl.addr_bits - pl.b1;
+#ifndef PK_LIT15
+#define PK_LIT15 0
+#endif
+    const uint32_t B = KC == 17 ? 512u : (PK_LIT15 && KC == 15) ? 128u : pl.B1, shift = KC == 17 ? 25u : (PK_LIT15 && KC == 15) ? 23u : pl.addr_bits - pl.b1;
     const uint32_t low_mask = shift >= 32 ? 0xffffffffu : ((1u << shift) - 1u);
-    const bool out16 = KC == 17 ? false : pl.b2 == 0;
+    const bool out16 = (KC == 17 || (PK_LIT15 && KC == 15)) ? false : pl.b2 == 0;
     const KT mask = (KT)((2u * k >= sizeof(KT) * 8u) ? ~(KT)0 : (((KT)1 << (2u * k)) - 1));
     const KT local_mask = (KT)((pl.addr_bits >= sizeof(KT) * 8u) ? ~(KT)0 : (((KT)1 << pl.addr_bits) - 1));   // SLICED: address inside the range
     uint32_t t = threadIdx.x;                                             // COUNT: the thread's place in the slot its WAVE samples (see locate)

@@ -25,6 +25,14 @@ constexpr int TILE = SC_T * SC_PER;  // 16384 records per tile = one FASTA chunk
 #ifndef PK_SB_L2
 #define PK_SB_L2 8
 #endif
+// experiments (tools/build_variant.sh): PK_CNT0 = count phase without per-record branches (empty slots add zero);
+// PK_UFULL = run write-out batches that lie wholly inside the tile skip the per-lane bounds test
+#ifndef PK_CNT0
+#define PK_CNT0 0
+#endif
+#ifndef PK_UFULL
+#define PK_UFULL 0
+#endif
 
 // ------------------------------------------------------------------ hot keys ---------------------
 // Tandem repeats (poly-A/T, (AT)n, (AAG)n ...) put tens of millions of identical canonical k-mers on a
@@ -173,7 +181,10 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
         // the tests: 1.42 -> 1.60 ms; a wave-uniform path without the tests for waves whose slots are all full: 1.32 -> 1.36)
 #pragma unroll
         for (int j = 0; j < PER; j++) {
-            if (FULL || ((okm >> j) & 1u)) __hip_atomic_fetch_add(&L.hist[digit_of(r[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (PK_CNT0 && !FULL) {
+                // no branch: an empty slot adds zero to the counter its (stale but in-range) digit names
+                __hip_atomic_fetch_add(&L.hist[digit_of(r[j])], (okm >> j) & 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (FULL || ((okm >> j) & 1u)) __hip_atomic_fetch_add(&L.hist[digit_of(r[j])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     if (!FULL && threadIdx.x < 64u) L.off[NB + threadIdx.x] = (uint32_t)TILE + threadIdx.x;   // where empty slots park (adds of zero)
@@ -207,6 +218,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     }
     __syncthreads();
     if (n_tile == ~0u) n_tile = L.total;
+    if (PK_UFULL) n_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_tile);   // uniform by construction; now in a scalar register
     // Parking.  PB == 0: record by record (returning add, then the write it places); every add is waited for on the spot
     // -- the compiler may not move an LDS write across the next atomic -- so a thread walks a chain of PER LDS round
     // trips, which the other waves of the CU cover.  PB > 0: PB returning adds back to back, then their PB writes --
@@ -287,12 +299,23 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
                     const uint32_t d0 = WIDE ? ((uint32_t)L.dig[p] & (uint32_t)(NB - 1)) : __builtin_amdgcn_ubfe(r0[u], shift, dbits);
                     g0[u] = L.gbase[d0];
                 }
+                // PK_UFULL: a batch that ends inside the tile (uniform test) stores without the per-lane bounds test
+                const bool whole = PK_UFULL && !FULL && (uint32_t)(j0 + SB) * NT <= n_tile;
+                if (PK_UFULL && whole) {
 #pragma unroll
-                for (int u = 0; u < SB; u++) {
-                    const uint32_t p = threadIdx.x + (uint32_t)(j0 + u) * NT;
-                    if (FULL || p < n_tile) {
+                    for (int u = 0; u < SB; u++) {
+                        const uint32_t p = threadIdx.x + (uint32_t)(j0 + u) * NT;
                         if (O16) o[p + g0[u]] = (uint16_t)(r0[u] & low_mask);
                         else o[p + g0[u]] = r0[u];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < SB; u++) {
+                        const uint32_t p = threadIdx.x + (uint32_t)(j0 + u) * NT;
+                        if (FULL || p < n_tile) {
+                            if (O16) o[p + g0[u]] = (uint16_t)(r0[u] & low_mask);
+                            else o[p + g0[u]] = r0[u];
+                        }
                     }
                 }
             }

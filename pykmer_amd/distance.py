@@ -6,11 +6,12 @@ scikit-bio / ete3 / xvfb dependencies (none is installed here): same inputs (`<p
 formula.  N is a dozen or so samples: plain numpy on the host, nothing for the GPU to do.
 
 Parity notes: the distance arithmetic restates calculate_distance.py:82-97 exactly.  The tree is
-built with the textbook Saitou-Nei neighbour joining that skbio.tree.nj implements (negative branch
-lengths clamped to zero, as skbio does by default); skbio itself is absent, so newick text layout,
-tie-breaking among equal Q entries and the lsmat float formatting are "parity unpinned" -- they are
-checked against the worked 5-taxon example quoted in calculate_distance.py:128-134 / the skbio docs.
-The PNG rendering (ete3 + xvfb) is not reproduced.
+built with the Saitou-Nei neighbour joining that skbio.tree.nj implements, in skbio's order of operations
+(see neighbor_joining); skbio itself is absent here, so the pin is the worked 5-taxon example the reference
+quotes at calculate_distance.py:128-134, whose newick and lsmat texts as the skbio documentation prints them
+are committed under tests/golden/ (nj_five_taxa.*).  Anything that example does not exercise (ties among
+equal Q entries, float formatting of other values) stays "parity unpinned".  The PNG rendering (ete3 + xvfb)
+is not reproduced.
 """
 import json
 import sys
@@ -64,37 +65,46 @@ def condensed_form(d: np.ndarray) -> np.ndarray:
 
 
 def neighbor_joining(dist: np.ndarray, ids: List[str]) -> str:
-    """Saitou & Nei (1987) neighbour joining -> newick string with branch lengths."""
+    """Saitou & Nei (1987) neighbour joining -> newick string with branch lengths, in the order of operations of
+    skbio.tree.nj (calculate_distance.py:189 calls it with result_constructor=str): the pair with the lowest Q is looked
+    for in the lower triangle row by row (first strict minimum wins ties), the member with the LARGER index is written
+    first, the joined node goes to the front of the id list, negative lengths and collapsed distances are clamped to
+    zero, and the last three nodes close as (ids[1], ids[0], ids[2]).  The 5-taxon example the reference quotes
+    (calculate_distance.py:128-134) therefore prints exactly what the skbio documentation shows
+    (tests/golden/nj_five_taxa.newick)."""
     n = len(ids)
     assert dist.shape == (n, n) and n >= 2
     d = dist.astype(np.float64).copy()
     nodes = [str(i) for i in ids]
     if n == 2:
         return f"({nodes[0]}:{d[0, 1] / 2:f}, {nodes[1]}:{d[0, 1] / 2:f});"
+
+    def member_lengths(d, i, j):
+        m = d.shape[0]
+        li = 0.5 * d[i, j] + (d[i].sum() - d[j].sum()) / (2 * (m - 2))
+        li = max(li, 0.0)                                       # disallow_negative_branch_length=True
+        lj = max(d[i, j] - li, 0.0)
+        return li, lj
+
     while len(nodes) > 3:
         m = len(nodes)
         r = d.sum(axis=1)
         q = (m - 2) * d - r[:, None] - r[None, :]
-        np.fill_diagonal(q, np.inf)
+        q[np.triu_indices(m)] = np.inf                          # lower triangle only, row-major: i > j
         i, j = np.unravel_index(np.argmin(q), q.shape)
-        if i > j:
-            i, j = j, i
-        li = 0.5 * d[i, j] + (r[i] - r[j]) / (2 * (m - 2))
-        lj = d[i, j] - li
-        li, lj = max(li, 0.0), max(lj, 0.0)                     # skbio: disallow_negative_branch_length=True
-        new = 0.5 * (d[i, :] + d[j, :] - d[i, j])
+        li, lj = member_lengths(d, i, j)
         label = f"({nodes[i]}:{li:f}, {nodes[j]}:{lj:f})"
         keep = [x for x in range(m) if x not in (i, j)]
+        new = np.maximum(0.5 * (d[i, keep] + d[j, keep] - d[i, j]), 0.0)
         nd = np.zeros((m - 1, m - 1))
         nd[1:, 1:] = d[np.ix_(keep, keep)]
-        nd[0, 1:] = nd[1:, 0] = new[keep]
+        nd[0, 1:] = nd[1:, 0] = new
         d = nd
         nodes = [label] + [nodes[x] for x in keep]
     # three nodes left: one unrooted trifurcation
-    l0 = max(0.5 * (d[0, 1] + d[0, 2] - d[1, 2]), 0.0)
-    l1 = max(0.5 * (d[0, 1] + d[1, 2] - d[0, 2]), 0.0)
-    l2 = max(0.5 * (d[0, 2] + d[1, 2] - d[0, 1]), 0.0)
-    return f"({nodes[0]}:{l0:f}, {nodes[1]}:{l1:f}, {nodes[2]}:{l2:f});"
+    l1, l2 = member_lengths(d, 1, 2)
+    l0 = max(0.5 * (d[1, 0] + d[2, 0] - d[1, 2]), 0.0)
+    return f"({nodes[1]}:{l1:f}, {nodes[0]}:{l0:f}, {nodes[2]}:{l2:f});"
 
 
 def _ascii(newick: str) -> str:

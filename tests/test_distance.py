@@ -29,6 +29,16 @@ def test_neighbor_joining_worked_example():
     expected tree (d:2, (c:4, (b:3, a:2):3):2, e:1)."""
     data = np.array([[0, 5, 9, 9, 8], [5, 0, 10, 10, 9], [9, 10, 0, 8, 7], [9, 10, 8, 0, 3], [8, 9, 7, 3, 0]], dtype=float)
     nw = distance.neighbor_joining(data, list("abcde"))
+    # the text skbio.tree.nj(dm, result_constructor=str) prints for this matrix in its documentation (skbio is absent here:
+    # the committed expected files hold that documented output, newick and lsmat layout)
+    import os
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    assert nw == "(d:2.000000, (c:4.000000, (b:3.000000, a:2.000000):3.000000):2.000000, e:1.000000);"
+    assert nw == open(os.path.join(golden, "nj_five_taxa.newick")).read()
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        distance.write_lsmat(os.path.join(tmp, "m.lsmat"), data, list("abcde"))
+        assert open(os.path.join(tmp, "m.lsmat")).read() == open(os.path.join(golden, "nj_five_taxa.lsmat")).read()
     assert nw.endswith(";") and nw.count("(") == nw.count(")") == 3
     assert _leaf_lengths(nw) == {"a": 2.0, "b": 3.0, "c": 4.0, "d": 2.0, "e": 1.0}
     assert re.search(r"\((a:2\.0+, b:3\.0+|b:3\.0+, a:2\.0+)\):3\.0+", nw)          # cherry (a,b) on a branch of length 3

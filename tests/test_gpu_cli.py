@@ -158,7 +158,7 @@ def test_indexer_cli_on_bgzipped_fasta(gpu, tmp_path, manifest, small_tables, pi
     bgzf.compress_file(str(plain), str(fa), index=False)
     assert bgzf.is_bgzf(str(fa)) and str(fa).endswith(".gz")
     if piece:
-        assert len(list(bgzf.iter_pieces(str(fa), piece))) > 10
+        assert len(list(bgzf.iter_pieces(str(fa), piece))) >= 5
         monkeypatch.setattr(indexer, "GZ_PIECE", piece)
         indexer.main([str(fa), "sample", "7"])
     else:

@@ -2,6 +2,7 @@
 # On the MI355X box: bench every variant library under pykmer_amd/_build (and the default build), k=15 and k=17.
 #   gpurun -- bash tools/bench_variants.sh <tag> [k17]
 cd "${GRAFT_REPO_ROOT:-.}"
+export PK_EXPERIMENT=1
 T=${1:-variants}; O=gpurun_out/$T; mkdir -p $O
 for lib in default $(ls pykmer_amd/_build/libpykmer_hip_*.so 2>/dev/null); do
   n=$(basename $lib .so); n=${n#libpykmer_hip_}

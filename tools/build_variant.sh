@@ -4,7 +4,10 @@
 set -e
 cd "$(dirname "$0")/../pykmer_amd/csrc"
 name=$1; shift
-mkdir -p ../_build
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-result -Wno-unused-value "$@" \
-  kmer_count.hip kmer_pack.hip kmer_fuse.hip kmer_part.hip gram_scan.hip pk_api.hip -o ../_build/libpykmer_hip_$name.so
+mkdir -p ../_build/$name
+for f in kmer_count kmer_pack kmer_fuse kmer_part gram_scan pk_api; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value "$@" -c $f.hip -o ../_build/$name/$f.o &
+done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC ../_build/$name/*.o -o ../_build/libpykmer_hip_$name.so
 echo ../_build/libpykmer_hip_$name.so

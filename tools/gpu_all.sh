@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 T=${1:-all}
 O=gpurun_out/$T
 mkdir -p $O
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q -s --durations=15 > $O/pytest.log 2>&1
+timeout -k 10 1000 python -m pytest tests -m gpu --maxfail=6 -q -s --durations=15 > $O/pytest.log 2>&1
 echo "pytest rc=$?" >> $O/pytest.log
 tail -30 $O/pytest.log
 grep -q "pytest rc=0" $O/pytest.log || exit 1
