@@ -210,8 +210,12 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_l1_reduce(const L1 *__restrict_
     tile_scan<L1>(i < n ? in[i] : 0u, 0u, sh, &tot, [](L1 a, L1 b) { return l1_compose(a, b); }, [](L1 v, int d) { return (L1)__shfl_up(v, d, 64); });
     if (threadIdx.x == 0) tile_tot[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(SCAN_T) void k_scan_l1_tiles(L1 *__restrict__ tile_tot, uint32_t n_tiles, Carry *carry) {
+// (also zeroes `n_zero` words at `zero_words`: the side-list length and the flags of the feed's partition passes -- one
+// stream operation less per feed; everything that writes or reads them is launched behind this kernel)
+__global__ __launch_bounds__(SCAN_T) void k_scan_l1_tiles(L1 *__restrict__ tile_tot, uint32_t n_tiles, Carry *carry, uint32_t *__restrict__ zero_words,
+                                                          uint32_t n_zero) {
     __shared__ L1 sh[SCAN_T / 64];
+    if (threadIdx.x < n_zero) zero_words[threadIdx.x] = 0u;
     L1 run = carry->l1;
     for (uint32_t t0 = 0; t0 < n_tiles; t0 += SCAN_T) {
         const uint32_t i = t0 + threadIdx.x;
@@ -310,10 +314,10 @@ void launch_chunk_l1(const uint8_t *fasta, uint64_t n, L1 *chunk_l1, uint32_t n_
     hipLaunchKernelGGL(k_chunk_l1, dim3((n_chunks + WG / 64 - 1) / (WG / 64)), dim3(WG), 0, s, fasta, n, n_chunks, chunk_l1);
 }
 // tile_ws: scratch for ceil(n_chunks / 1024) summaries of the respective type
-void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, L1 *tile_ws, hipStream_t s) {
+void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, L1 *tile_ws, uint32_t *zero_words, uint32_t n_zero, hipStream_t s) {
     const uint32_t n_tiles = (n_chunks + SCAN_T - 1) / SCAN_T;
     hipLaunchKernelGGL(k_scan_l1_reduce, dim3(n_tiles), dim3(SCAN_T), 0, s, in, n_chunks, tile_ws);
-    hipLaunchKernelGGL(k_scan_l1_tiles, dim3(1), dim3(SCAN_T), 0, s, tile_ws, n_tiles, carry);
+    hipLaunchKernelGGL(k_scan_l1_tiles, dim3(1), dim3(SCAN_T), 0, s, tile_ws, n_tiles, carry, zero_words, n_zero);
     hipLaunchKernelGGL(k_scan_l1_apply, dim3(n_tiles), dim3(SCAN_T), 0, s, in, n_chunks, (const L1 *)tile_ws, out);
 }
 void launch_chunk_l2(const uint8_t *fasta, uint64_t n, const L1 *st1, L2 *chunk_l2, LaneState *lane_state, PiecePack *packs, uint32_t *chunk_odd, uint32_t n_chunks,

@@ -501,13 +501,19 @@ __global__ __launch_bounds__(1024) void k_level1_finish(const uint32_t *__restri
     }
 }
 
-// column sums of the per-workgroup tally rows of the sampling launch
+// column sums of the per-workgroup tally rows of the sampling launch: one thread per column, every row (coalesced across the
+// workgroup), the sum stored -- not added, so nothing has to be zeroed first
 __global__ __launch_bounds__(256) void k_tally_sum(const uint32_t *__restrict__ rows, uint32_t n_rows, uint32_t n_cols, uint32_t *__restrict__ tot) {
     const uint32_t col = blockIdx.x * 256u + threadIdx.x;
     if (col >= n_cols) return;
-    uint32_t acc = 0;
-    for (uint32_t r = blockIdx.y; r < n_rows; r += gridDim.y) acc += rows[(uint64_t)r * n_cols + col];
-    if (acc) atomicAdd(&tot[col], acc);
+    uint32_t acc[4] = {0, 0, 0, 0};
+    uint32_t r = 0;
+    for (; r + 4 <= n_rows; r += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] += rows[(uint64_t)(r + u) * n_cols + col];
+    }
+    for (; r < n_rows; r++) acc[0] += rows[(uint64_t)r * n_cols + col];
+    tot[col] = acc[0] + acc[1] + acc[2] + acc[3];
 }
 
 // ------------------------------------------------------------------ launchers -------------------
@@ -560,12 +566,10 @@ void launch_provision(const uint32_t *codes, const uint32_t *restarts, const uin
     const uint32_t grid = n_sampled < COUNT_WGS ? n_sampled : COUNT_WGS;
     const uint32_t n_tally = pl.n_tally;
     const uint32_t tally_shift = n_tally > pl.B1 ? pl.fb_bits : pl.addr_bits - pl.b1;
-    hipMemsetAsync(tally_tot, 0, (size_t)n_tally * sizeof(uint32_t), s);
     launch_ws<true>(pl, grid, (size_t)n_tally * 4, s, codes, restarts, n_bases, st2, pl, n_sampled, stride, (void *)nullptr, (uint32_t *)nullptr,
                     (const uint32_t *)nullptr, 0u, flags, tally_shift, n_tally, tally_rows, (unsigned long long *)nullptr,
                     (unsigned long long *)nullptr, (uint64_t)0);
-    hipLaunchKernelGGL(k_tally_sum, dim3((n_tally + 255u) / 256u, grid < 16u ? 1u : 16u), dim3(256), 0, s, (const uint32_t *)tally_rows, grid, n_tally,
-                       tally_tot);
+    hipLaunchKernelGGL(k_tally_sum, dim3((n_tally + 255u) / 256u), dim3(256), 0, s, (const uint32_t *)tally_rows, grid, n_tally, tally_tot);
     hipLaunchKernelGGL(k_provision, dim3(1), dim3(1024), 0, s, (const uint32_t *)tally_tot, n_tally, pl, n_sampled, stride, bucket_base, cursor1, cap_end,
                        final_start, cursor2, cap2_end, flags);
 }

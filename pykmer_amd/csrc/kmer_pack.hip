@@ -143,7 +143,15 @@ __global__ __launch_bounds__(WG, PK_LB_SQ) void k_squeeze(const uint8_t *__restr
                                                 const uint32_t *__restrict__ chunk_odd, uint32_t k_arg, uint32_t n_chunks, uint32_t chunks_per_wg,
                                                 uint32_t *__restrict__ codes,
                                                 uint32_t *__restrict__ restarts, uint32_t *__restrict__ n_bases,
-                                                DevRec *__restrict__ recs, uint64_t recs_cap, Carry *carry) {
+                                                DevRec *__restrict__ recs, uint64_t recs_cap, Carry *carry, uint32_t *__restrict__ flags) {
+    // The record array was sized before this feed's records were counted (no host round trip between the structure pass and
+    // this kernel).  The count is known here -- the structure pass's scan left it in `carry` -- so if the array is too
+    // small every workgroup returns before touching anything, flags[0] = 2 keeps the later kernels of the feed away, and
+    // the host grows the array and repeats from here.
+    if (carry->n_recs > recs_cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) flags[0] = 2u;
+        return;
+    }
     __shared__ __attribute__((aligned(16))) uint8_t image[2][CHUNK];   // text of chunks that hold pieces for the byte-wise machine
     __shared__ __attribute__((aligned(16))) uint32_t slot_codes[SLOT_CODE_WORDS + 8];   // + slack: lds_or_bits touches up to 5 words
     __shared__ __attribute__((aligned(16))) uint32_t slot_rst[SLOT_RST_WORDS + 8];
@@ -286,14 +294,14 @@ __global__ __launch_bounds__(WG, PK_LB_SQ) void k_squeeze(const uint8_t *__restr
 
 void launch_squeeze(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const PiecePack *packs, const L2 *st2,
                     const uint32_t *chunk_odd, uint32_t k, uint32_t n_chunks, uint32_t n_wg, uint32_t chunks_per_wg, uint32_t *codes, uint32_t *restarts, uint32_t *n_bases,
-                    DevRec *recs, uint64_t recs_cap, Carry *carry, hipStream_t s) {
+                    DevRec *recs, uint64_t recs_cap, Carry *carry, uint32_t *flags, hipStream_t s) {
     static const bool lit = !(getenv("PK_K15") && atoi(getenv("PK_K15")) == 0);
     if (lit && k == 15) hipLaunchKernelGGL(k_squeeze<15>, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, packs, st2, chunk_odd, k, n_chunks, chunks_per_wg, codes,
-                                           restarts, n_bases, recs, recs_cap, carry);
+                                           restarts, n_bases, recs, recs_cap, carry, flags);
     else if (lit && k == 17) hipLaunchKernelGGL(k_squeeze<17>, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, packs, st2, chunk_odd, k, n_chunks, chunks_per_wg, codes,
-                                                restarts, n_bases, recs, recs_cap, carry);
+                                                restarts, n_bases, recs, recs_cap, carry, flags);
     else hipLaunchKernelGGL(k_squeeze<0>, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, packs, st2, chunk_odd, k, n_chunks, chunks_per_wg, codes,
-                            restarts, n_bases, recs, recs_cap, carry);
+                            restarts, n_bases, recs, recs_cap, carry, flags);
 }
 
 }  // namespace pk

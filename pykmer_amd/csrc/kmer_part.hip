@@ -310,7 +310,6 @@ __global__ __launch_bounds__(NT, 4) void k_scatter2(const uint32_t *__restrict__
 // counter (<= 255 + 65024) can never carry into its neighbour.
 constexpr uint32_t K6_PIECE = 65024;   // multiple of 8
 constexpr int K6_BYTES_LDS = 65536 + 1024 + 128;   // k_bucket_count_bytes: slice image, histogram bins, wrap flag
-constexpr uint32_t HIST_REPLICAS = 64; // copies of the 256-bin histogram delta the bucket-count workgroups add into
 
 // `fresh` = first feed after a reset: the table holds nothing yet (it is not even zeroed), so slices
 // are not read back and buckets without records are written as zeros.
@@ -708,12 +707,16 @@ void k_bucket_count_bytes(const uint16_t *__restrict__ recs, const uint32_t *__r
     }
 }
 
-// sums the per-bucket histogram rows into the running 256-bin histogram (signed deltas: two's complement adds)
-__global__ __launch_bounds__(256) void k_hist_reduce(const unsigned long long *__restrict__ hist_rep, unsigned long long *__restrict__ hist,
-                                                     const uint32_t *__restrict__ flags) {
-    if (flags[0]) return;
-    unsigned long long acc = 0;                                          // signed deltas: two's complement adds
-    for (uint32_t r = 0; r < HIST_REPLICAS; r++) acc += hist_rep[(uint64_t)r * 256 + threadIdx.x];
+// sums the HIST_REPLICAS copies of the feed's histogram change into the running 256-bin histogram (signed deltas: two's
+// complement adds) and leaves the copies zeroed for the next feed (they are zeroed once more when the workspace is
+// allocated): called by the first workgroup of k_apply_side, 256 threads of it
+__device__ __forceinline__ void hist_reduce(unsigned long long *__restrict__ hist_rep, unsigned long long *__restrict__ hist) {
+    if (threadIdx.x >= 256) return;
+    unsigned long long acc = 0;
+    for (uint32_t r = 0; r < HIST_REPLICAS; r++) {
+        acc += hist_rep[(uint64_t)r * 256 + threadIdx.x];
+        hist_rep[(uint64_t)r * 256 + threadIdx.x] = 0ull;
+    }
     if (acc) atomicAdd(&hist[threadIdx.x], acc);
 }
 
@@ -743,9 +746,11 @@ __device__ __forceinline__ void table_sat_add(uint8_t *table8, uint64_t addr, ui
 
 __global__ __launch_bounds__(WG) void k_apply_side(const unsigned long long *__restrict__ side, const unsigned long long *__restrict__ side_n,
                                                    uint64_t side_cap, uint8_t *__restrict__ table8, unsigned long long *__restrict__ hist,
-                                                   const uint32_t *__restrict__ flags) {
+                                                   unsigned long long *__restrict__ hist_rep, const uint32_t *__restrict__ flags) {
     __shared__ unsigned long long key[AS_SLOTS];
     if (flags[0]) return;
+    static_assert(WG >= 256, "one thread per histogram bin");
+    if (blockIdx.x == 0) hist_reduce(hist_rep, hist);       // the bucket-count kernel's histogram change (launched before this one)
     __shared__ uint32_t val[AS_SLOTS];
     __shared__ int dh[256];                                              // this workgroup's change to the value histogram
     unsigned long long n = *side_n;
@@ -860,7 +865,6 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
     lay->side_cap = n_bytes + 16;                          // every side entry stands for >= 1 k-mer
     lay->side = o; o += up((size_t)lay->side_cap * 8);
     lay->side_n = o; o += 256;                             // side-list length (u64), then the flags word
-    lay->bucket_hist = o; o += up((size_t)HIST_REPLICAS * 256 * 8);         // replicated histogram deltas of one feed
     return o;
 }
 
@@ -897,7 +901,7 @@ static bool pk_bytes_enabled() {                                         // PK_K
 // caller reads the flags word back to learn whether the layout held (flags[0] == 0).
 int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint32_t stride, uint8_t *ws, const PartWorkspace &lay, uint8_t *table8,
                        hipStream_t s, hipEvent_t ev_sort_begin, hipEvent_t ev_sort_end, hipEvent_t ev_part_end, bool fresh,
-                       unsigned long long *hist) {
+                       unsigned long long *hist, unsigned long long *bucket_hist, bool armed) {
     const uint32_t *codes = (const uint32_t *)(ws + lay.codes), *restarts = (const uint32_t *)(ws + lay.restarts);
     const uint32_t *n_bases = (const uint32_t *)(ws + lay.n_bases);
     uint32_t *tally_rows = (uint32_t *)(ws + lay.tally_rows), *tally_tot = (uint32_t *)(ws + lay.tally_tot);
@@ -912,7 +916,7 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     const uint32_t nfb = pl.B1 * pl.B2;
     const bool laid_out2 = pl.n_tally > pl.B1 || pl.sample2;
     if (pl.B1 > (pl.k <= 15 ? 128u : 512u) || pl.B2 > 512u || pl.fb_bits > 16u) return -3;   // what the kernels' LDS arrays are sized for
-    if (hipMemsetAsync(side_n, 0, 16, s) != hipSuccess) return -2;   // side-list length + flags
+    if (!armed && hipMemsetAsync(side_n, 0, PART_FLAG_WORDS * 4, s) != hipSuccess) return -2;   // side-list length + flags
     launch_provision(codes, restarts, n_bases, st2, pl, stride, tally_rows, tally_tot, bucket_base, cursor1, cap_end, final_start, cursor2, cap2_end,
                      flags, s);
     if (ev_sort_begin) hipEventRecord(ev_sort_begin, s);
@@ -961,10 +965,8 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     const uint32_t split = sparse ? 1u : 0u;
     const size_t part_addrs = (size_t)1 << (pl.fb_bits - split);
     const size_t lds6 = part_addrs * 2 < 64 ? 64 : part_addrs * 2;
-    unsigned long long *bucket_hist = (unsigned long long *)(ws + lay.bucket_hist);
     const uint32_t n_rows6 = (uint32_t)(nfb << split);
     if (split > 1u) return -3;                                           // the kernels are laid out for whole and half buckets
-    if (hipMemsetAsync(bucket_hist, 0, (size_t)HIST_REPLICAS * 256 * 8, s) != hipSuccess) return -2;
     if (pl.fb_bits == 15 && fresh)                                       // 64 KiB of counters: two workgroups per CU
         hipLaunchKernelGGL((k_bucket_count_half_lean<1024, true>), dim3(n_rows6), dim3(1024), lds6, s, final_recs, k6_start, k6_end, pl.fb_bits, split, table8,
                            fresh ? 1u : 0u, bucket_hist, (const uint32_t *)flags);
@@ -980,8 +982,7 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     else
         hipLaunchKernelGGL(k_bucket_count<1024>, dim3(n_rows6), dim3(1024), lds6, s, final_recs, k6_start, k6_end, pl.fb_bits, split, table8,
                            fresh ? 1u : 0u, bucket_hist, (const uint32_t *)flags);
-    hipLaunchKernelGGL(k_hist_reduce, dim3(1), dim3(256), 0, s, (const unsigned long long *)bucket_hist, hist, (const uint32_t *)flags);
-    hipLaunchKernelGGL(k_apply_side, dim3(AS_WGS), dim3(WG), 0, s, side, side_n, lay.side_cap, table8, hist, (const uint32_t *)flags);
+    hipLaunchKernelGGL(k_apply_side, dim3(AS_WGS), dim3(WG), 0, s, side, side_n, lay.side_cap, table8, hist, bucket_hist, (const uint32_t *)flags);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

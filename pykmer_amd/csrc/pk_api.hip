@@ -202,9 +202,10 @@ struct pk_indexer {
     uint8_t *table8 = nullptr;       // the .kin image
     Carry *carry = nullptr;
     Carry *carry0 = nullptr;           // the parser state of an empty stream (device copy: a reset is a device-to-device copy, no host wait)
-    struct Pinned { Carry carry; unsigned long long hist[256]; uint64_t n_recs; uint32_t flags[2]; } *pin = nullptr;   // pinned landing zone of the small read-backs
+    struct Pinned { Carry carry; unsigned long long hist[256]; uint64_t n_recs; uint32_t flags[4]; } *pin = nullptr;   // pinned landing zone of the small read-backs
     bool zero_timed = true;            // t_zero of the last reset has been read from its events
     unsigned long long *hist = nullptr;
+    unsigned long long *hist_rep = nullptr;   // HIST_REPLICAS copies of one feed's histogram change (zero between feeds)
     DevRec *recs = nullptr;
     uint64_t recs_cap = 0;
     L1 *c_l1 = nullptr, *c_l1s = nullptr;
@@ -260,7 +261,7 @@ extern "C" void pk_indexer_destroy(pk_indexer *ix) {
     if (!ix) return;
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
-    hipFree(ix->table8); hipFree(ix->carry); hipFree(ix->carry0); hipFree(ix->hist); hipFree(ix->recs);
+    hipFree(ix->table8); hipFree(ix->carry); hipFree(ix->carry0); hipFree(ix->hist); hipFree(ix->hist_rep); hipFree(ix->recs);
     if (ix->pin) hipHostFree(ix->pin);
     hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state); hipFree(ix->packs); hipFree(ix->chunk_odd); hipFree(ix->t_l1); hipFree(ix->t_l2); hipFree(ix->staging[0]); hipFree(ix->staging[1]); hipFree(ix->ws);
     for (auto &e : ix->ev) if (e) hipEventDestroy(e);
@@ -304,6 +305,14 @@ extern "C" int pk_indexer_create_slice(pk_indexer **out, int k, int device, int 
         if ((e = hipMemcpy(ix->carry0, &c, sizeof c, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(carry0)");
     }
     if ((e = hipMalloc(&ix->hist, 256 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(hist)");
+    if ((e = hipMalloc(&ix->hist_rep, (size_t)HIST_REPLICAS * 256 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(hist replicas)");
+    if ((e = hipMemset(ix->hist_rep, 0, (size_t)HIST_REPLICAS * 256 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(hist replicas)");
+    {
+        // room for the records of small inputs from the start: the squeeze pass checks the capacity itself (see feed_piece)
+        const uint64_t cap = 4096;
+        if ((e = hipMalloc(&ix->recs, cap * sizeof(DevRec))) != hipSuccess) return bail(e, "hipMalloc(records)");
+        ix->recs_cap = cap;
+    }
     part_set_attributes();                               // dynamic-LDS opt-ins, once per process and device
     rc = ix_reset(ix);
     if (rc) { std::string keep = g_err; pk_indexer_destroy(ix); g_err = keep; return rc; }
@@ -375,19 +384,6 @@ static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
     const uint32_t n_chunks = (uint32_t)((n_bytes + CHUNK - 1) / CHUNK);
     int rc = ensure_chunks(ix, n_chunks);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(ix->ev[0], ix->stream));
-    launch_chunk_l1(f, n_bytes, ix->c_l1, n_chunks, ix->stream);
-    launch_scan_l1(ix->c_l1, n_chunks, ix->carry, ix->c_l1s, ix->t_l1, ix->stream);
-    launch_chunk_l2(f, n_bytes, ix->c_l1s, ix->c_l2, ix->lane_state, ix->packs, ix->chunk_odd, n_chunks, (uint32_t)ix->k, ix->stream);
-    launch_scan_l2(ix->c_l2, n_chunks, ix->carry, ix->c_l2s, ix->t_l2, (uint32_t)ix->k, ix->stream);
-    HIPCHK(hipEventRecord(ix->ev[1], ix->stream));
-    HIPCHK(hipMemcpyAsync(&ix->pin->n_recs, &ix->carry->n_recs, sizeof(uint64_t), hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    time_reset(ix);
-    const uint64_t n_recs = ix->pin->n_recs;
-    rc = ensure_recs(ix, n_recs);
-    if (rc) return rc;
-    ix->n_recs = n_recs;
     PartPlan pl = make_part_plan((uint32_t)ix->k, n_bytes, (uint32_t)ix->slice_bits, (uint32_t)ix->slice_index);
     if (!plan_fits_u32(pl)) return fail(PK_ERR_ARG, "feed of %llu bytes needs record positions beyond 2^32 (internal limit); split it", (unsigned long long)n_bytes);
     PartWorkspace lay;
@@ -397,26 +393,62 @@ static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
         HIPCHK(hipMalloc(&ix->ws, need));
         ix->ws_cap = need;
     }
-    HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
-    launch_squeeze(f, n_bytes, ix->bytes_fed, ix->lane_state, ix->packs, ix->c_l2s, ix->chunk_odd, (uint32_t)ix->k, n_chunks, pl.n_wg0, pl.G, (uint32_t *)(ix->ws + lay.codes),
-                   (uint32_t *)(ix->ws + lay.restarts), (uint32_t *)(ix->ws + lay.n_bases), ix->recs, ix->recs_cap, ix->carry, ix->stream);
-    HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
+    uint32_t *flag_words = (uint32_t *)(ix->ws + lay.side_n);              // side-list length (u64), then flags[4]
+    uint32_t *flags = flag_words + 2;
+    // Nothing between here and the last kernel of the feed waits for the device: the record array was sized from what the
+    // feeds so far held (ensure_recs below, after the feed), the squeeze pass checks that against the count the structure
+    // pass leaves in `carry` and backs out if it does not fit (flags[0] = 2), the sorts back out if a sampled bucket
+    // room does not hold (flags[0] = 1), and the host reads flags + record count once, behind the last kernel.
+    HIPCHK(hipEventRecord(ix->ev[0], ix->stream));
+    launch_chunk_l1(f, n_bytes, ix->c_l1, n_chunks, ix->stream);
+    launch_scan_l1(ix->c_l1, n_chunks, ix->carry, ix->c_l1s, ix->t_l1, flag_words, PART_FLAG_WORDS, ix->stream);
+    launch_chunk_l2(f, n_bytes, ix->c_l1s, ix->c_l2, ix->lane_state, ix->packs, ix->chunk_odd, n_chunks, (uint32_t)ix->k, ix->stream);
+    launch_scan_l2(ix->c_l2, n_chunks, ix->carry, ix->c_l2s, ix->t_l2, (uint32_t)ix->k, ix->stream);
+    HIPCHK(hipEventRecord(ix->ev[1], ix->stream));
     float a = 0, b = 0, c = 0, d = 0, e = 0;
-    // the level-1 buckets are laid out from a sample of the slots; if one of them runs out of room every later kernel
-    // returns untouched (flags[0]) and the passes behind the squeeze are repeated with exact sizes
-    for (uint32_t stride = pl.sample_stride;; stride = 1) {
+    bool armed = true;                                       // the scan kernel zeroed the flag words for the first attempt
+    bool squeeze = true;
+    uint32_t stride = pl.sample_stride;
+    for (int attempt = 0;; attempt++) {
+        if (squeeze) {
+            if (!armed) HIPCHK(hipMemsetAsync(flag_words, 0, PART_FLAG_WORDS * 4, ix->stream));
+            HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
+            launch_squeeze(f, n_bytes, ix->bytes_fed, ix->lane_state, ix->packs, ix->c_l2s, ix->chunk_odd, (uint32_t)ix->k, n_chunks, pl.n_wg0, pl.G, (uint32_t *)(ix->ws + lay.codes),
+                           (uint32_t *)(ix->ws + lay.restarts), (uint32_t *)(ix->ws + lay.n_bases), ix->recs, ix->recs_cap, ix->carry, flags, ix->stream);
+            HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
+            armed = true;
+        }
+        // the level-1 buckets are laid out from a sample of the slots; if one of them runs out of room every later kernel
+        // returns untouched (flags[0]) and the passes behind the squeeze are repeated with exact sizes
         if (launch_partitioned(ix->c_l2s, n_bytes, pl, stride, ix->ws, lay, ix->table8, ix->stream, ix->ev[10], ix->ev[11], ix->ev[8],
-                               ix->table_fresh, ix->hist))
+                               ix->table_fresh, ix->hist, ix->hist_rep, armed))
             return fail(PK_ERR_HIP, "partition pipeline launch failed: %s", hipGetErrorString(hipGetLastError()));
         HIPCHK(hipEventRecord(ix->ev[9], ix->stream));
-        volatile uint32_t *flags = ix->pin->flags;
-        HIPCHK(hipMemcpyAsync(ix->pin->flags, ix->ws + lay.side_n + 8, sizeof ix->pin->flags, hipMemcpyDeviceToHost, ix->stream));
+        volatile uint32_t *got = ix->pin->flags;
+        HIPCHK(hipMemcpyAsync(ix->pin->flags, flags, sizeof ix->pin->flags, hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipMemcpyAsync(&ix->pin->n_recs, &ix->carry->n_recs, sizeof(uint64_t), hipMemcpyDeviceToHost, ix->stream));
         HIPCHK(hipStreamSynchronize(ix->stream));
         HIPCHK(hipGetLastError());
-        if (!flags[0]) { ix->recounted += flags[1]; break; }
-        if (stride == 1) return fail(PK_ERR_HIP, "level-1 buckets overflowed an exact layout (internal error)");
-        ix->relayouts++;
+        time_reset(ix);
+        if (!got[0]) { ix->recounted += got[1]; break; }
+        if (attempt >= 3) return fail(PK_ERR_HIP, "the feed's layout did not settle (internal error, flag %u)", got[0]);
+        armed = false;
+        if (got[0] == 2u) {                                  // more records than the array holds: grow it, squeeze again
+            rc = ensure_recs(ix, ix->pin->n_recs);
+            if (rc) return rc;
+            squeeze = true;
+        } else {                                             // a bucket outgrew its sampled room: lay out again, exactly
+            if (stride == 1) return fail(PK_ERR_HIP, "level-1 buckets overflowed an exact layout (internal error)");
+            stride = 1;
+            squeeze = false;
+            ix->relayouts++;
+        }
     }
+    const uint64_t recs_before = ix->n_recs;
+    ix->n_recs = ix->pin->n_recs;
+    // room for the next feed's records before it arrives: as many again as this feed brought, and then some
+    rc = ensure_recs(ix, ix->n_recs + 2 * (ix->n_recs - recs_before) + 1024);
+    if (rc) return rc;
     ix->table_fresh = false;
     HIPCHK(hipEventElapsedTime(&a, ix->ev[0], ix->ev[1]));
     HIPCHK(hipEventElapsedTime(&b, ix->ev[2], ix->ev[3]));

@@ -26,7 +26,7 @@ struct Carry {
 };
 
 void launch_chunk_l1(const uint8_t *fasta, uint64_t n, L1 *chunk_l1, uint32_t n_chunks, hipStream_t s);
-void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, L1 *tile_ws, hipStream_t s);
+void launch_scan_l1(const L1 *in, uint32_t n_chunks, Carry *carry, L1 *out, L1 *tile_ws, uint32_t *zero_words, uint32_t n_zero, hipStream_t s);
 void launch_chunk_l2(const uint8_t *fasta, uint64_t n, const L1 *st1, L2 *chunk_l2, LaneState *lane_state, PiecePack *packs, uint32_t *chunk_odd, uint32_t n_chunks,
                      uint32_t k, hipStream_t s);
 void launch_scan_l2(const L2 *in, uint32_t n_chunks, Carry *carry, L2 *out, L2 *tile_ws, uint32_t k, hipStream_t s);
@@ -37,7 +37,7 @@ constexpr uint32_t SLOT_CODE_WORDS = 1024;   // 16384 bases x 2 bits
 constexpr uint32_t SLOT_RST_WORDS = 512;     // 16384 restart bits
 void launch_squeeze(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const LaneState *lane_state, const PiecePack *packs, const L2 *st2,
                     const uint32_t *chunk_odd, uint32_t k, uint32_t n_chunks, uint32_t n_wg, uint32_t chunks_per_wg, uint32_t *codes, uint32_t *restarts, uint32_t *n_bases,
-                    DevRec *recs, uint64_t recs_cap, Carry *carry, hipStream_t s);
+                    DevRec *recs, uint64_t recs_cap, Carry *carry, uint32_t *flags, hipStream_t s);
 
 // kmer_fuse.hip / kmer_part.hip -- partitioned table update
 struct PartPlan {
@@ -61,7 +61,7 @@ struct PartPlan {
 constexpr uint32_t COUNT_WGS = 256;   // workgroups (= tally rows) of the sampling launch
 struct PartWorkspace {       // byte offsets into one device allocation
     size_t codes, restarts, n_bases, tally_rows, tally_tot, bucket_base, bucket_end, compact_base, cursor1, cap_end, wg2_start, final_start, cursor2,
-        cap2_end, out1, hist2, rowoff2, out2, side, side_n, bucket_hist;
+        cap2_end, out1, hist2, rowoff2, out2, side, side_n;
     uint64_t side_cap;
 };
 PartPlan make_part_plan(uint32_t k, uint64_t n_bytes, uint32_t slice_bits, uint32_t slice_index);
@@ -75,9 +75,13 @@ void launch_walk_sort(const uint32_t *codes, const uint32_t *restarts, const uin
                       uint32_t *cursor1, const uint32_t *cap_end, uint32_t *flags, const uint32_t *bucket_base, uint32_t *bucket_end,
                       uint32_t *compact_base, uint32_t *wg2_start, unsigned long long *side, unsigned long long *side_n, uint64_t side_cap,
                       hipStream_t s);
+// `armed`: the side-list length and the flags word were already zeroed on the stream (launch_scan_l1 does it for the first
+// attempt of a feed); a repeat after an overflow zeroes them itself.
 int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint32_t stride, uint8_t *ws, const PartWorkspace &lay, uint8_t *table8,
                        hipStream_t s, hipEvent_t ev_sort_begin, hipEvent_t ev_sort_end, hipEvent_t ev_part_end, bool fresh,
-                       unsigned long long *hist);
+                       unsigned long long *hist, unsigned long long *hist_replicas, bool armed);
+constexpr uint32_t HIST_REPLICAS = 64;   // copies of the 256-bin histogram change the bucket-count workgroups add into (zeroed by their reader, k_apply_side)
+constexpr uint32_t PART_FLAG_WORDS = 6;   // side_n (u64) + flags[4], zeroed together
 
 // gram_scan.hip
 // tables: device array of N device pointers, each n_slice bytes (16-byte aligned).  pair: device N*N u64,
