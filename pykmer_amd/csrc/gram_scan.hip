@@ -262,24 +262,26 @@ __global__ __launch_bounds__(MAXT) void k_gram_mw(const uint8_t *const *__restri
     const uint64_t n_tiles = (n_words + TW - 1) / TW;
     const int items = NBT * TW;
     uint4 ra[ITEMS], rb[ITEMS];
-    auto fetch = [&](uint64_t tile) {
+    auto fetch_item = [&](uint64_t tile, int m) {
         const uint64_t w0 = tile * TW;
-#pragma unroll
-        for (int m = 0; m < ITEMS; m++) {
-            const int q = threadIdx.x + m * nthreads;
-            const int t = __builtin_amdgcn_readfirstlane(q / TW), w = q % TW;
-            ra[m] = make_uint4(0, 0, 0, 0); rb[m] = ra[m];
-            if (q < items && t < N && w0 + w < n_words && tile < n_tiles) load_word(tables[t], w0 + w, n, ra[m], rb[m]);
-        }
+        const int q = threadIdx.x + m * nthreads;
+        const int t = __builtin_amdgcn_readfirstlane(q / TW), w = q % TW;
+        ra[m] = make_uint4(0, 0, 0, 0); rb[m] = ra[m];
+        if (q < items && t < N && w0 + w < n_words && tile < n_tiles) load_word(tables[t], w0 + w, n, ra[m], rb[m]);
     };
-    fetch(blockIdx.x);
+#pragma unroll
+    for (int m = 0; m < ITEMS; m++) fetch_item(blockIdx.x, m);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        // phase 1: the tile's (table, word) items -> one mask per window in LDS
+        // phase 1: the tile's (table, word) items -> one mask per window in LDS.  An item's registers are free as soon as
+        // its bit planes exist, so the SAME item of the next tile is requested right there: a whole iteration (the rest
+        // of this phase, both barriers and the tallies) covers its latency, with no second set of registers.  (Requested
+        // only after the first barrier, a 2-window sweep at N = 13 ran at 2.6 TB/s: nothing but latency.)
 #pragma unroll
         for (int m = 0; m < ITEMS; m++) {
             const int q = threadIdx.x + m * nthreads;
-            if (q >= items) continue;
             uint32_t p[8] = {ra[m].x, ra[m].y, ra[m].z, ra[m].w, rb[m].x, rb[m].y, rb[m].z, rb[m].w};
+            fetch_item(tile + gridDim.x, m);
+            if (q >= items) continue;
             bit_transpose8(p);
             uint32_t ge_lo = 0, prev_lo = 0;
             // rolled: unrolled, the compiler hoists the 8 x 16 uniform bit masks of all thresholds out of the tile loop and
@@ -294,7 +296,6 @@ __global__ __launch_bounds__(MAXT) void k_gram_mw(const uint8_t *const *__restri
             }
         }
         __syncthreads();
-        fetch(tile + gridDim.x);                                         // lands while the tallies below run
         // phase 2: every wave tallies its (window, 8x8 pair block) slots over the tile's words.  Only pairs that exist are
         // tallied: rows / columns past the last table and, in a diagonal block, the lower triangle are skipped by uniform
         // branches (N = 13: 91 of the 192 pair slots of its three blocks) -- this phase is vector-issue bound.

@@ -31,7 +31,7 @@ constexpr int TILE = SC_T * SC_PER;  // 16384 records per tile = one FASTA chunk
 #define PK_CNT0 0
 #endif
 #ifndef PK_UFULL
-#define PK_UFULL 0
+#define PK_UFULL 1          // k = 15: level 1 1.314 -> 1.285 ms (PK_CNT0: 1.68 ms -- the holes' LDS adds cost more than their branches)
 #endif
 
 // ------------------------------------------------------------------ hot keys ---------------------

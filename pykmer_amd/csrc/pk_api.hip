@@ -200,9 +200,12 @@ struct pk_indexer {
     uint64_t n = 0;                  // table bytes: 4^k / 2^slice_bits
     hipStream_t stream = nullptr;
     uint8_t *table8 = nullptr;       // the .kin image
-    Carry *carry = nullptr;
-    Carry *carry0 = nullptr;           // the parser state of an empty stream (device copy: a reset is a device-to-device copy, no host wait)
-    struct Pinned { Carry carry; unsigned long long hist[256]; uint64_t n_recs; uint32_t flags[4]; } *pin = nullptr;   // pinned landing zone of the small read-backs
+    // parser state + running totals, and the value histogram, side by side: one copy brings both to the host, one copy resets both
+    struct Tail { Carry carry; unsigned long long hist[256]; };
+    Tail *tail = nullptr, *tail0 = nullptr;   // tail0: the state of an empty stream (a reset is a device-to-device copy, no host wait)
+    Carry *carry = nullptr;            // = &tail->carry
+    struct Pinned { Tail tail; uint32_t flags[4]; } *pin = nullptr;   // pinned landing zone of the small read-backs
+    bool tail_on_host = false;         // pin->tail is what the device holds (the last feed brought it along with its flags)
     bool zero_timed = true;            // t_zero of the last reset has been read from its events
     unsigned long long *hist = nullptr;
     unsigned long long *hist_rep = nullptr;   // HIST_REPLICAS copies of one feed's histogram change (zero between feeds)
@@ -235,8 +238,8 @@ static int ix_reset(pk_indexer *ix) {
     // the first feed writes every slice of the u8 table itself (k_bucket_count, fresh); the table is only
     // zeroed if nothing gets fed at all (see pk_indexer_finish).  Nothing here waits for the device: the stream orders
     // the reset behind whatever is still running, and its duration is read at the next point that waits anyway.
-    HIPCHK(hipMemcpyAsync(ix->carry, ix->carry0, sizeof(Carry), hipMemcpyDeviceToDevice, ix->stream));
-    HIPCHK(hipMemsetAsync(ix->hist, 0, 256 * sizeof(unsigned long long), ix->stream));
+    HIPCHK(hipMemcpyAsync(ix->tail, ix->tail0, sizeof(pk_indexer::Tail), hipMemcpyDeviceToDevice, ix->stream));
+    ix->tail_on_host = false;
     if (ix->recs) HIPCHK(hipMemsetAsync(ix->recs, 0, ix->recs_cap * sizeof(DevRec), ix->stream));
     HIPCHK(hipEventRecord(ix->ev[7], ix->stream));
     ix->zero_timed = false;
@@ -261,7 +264,7 @@ extern "C" void pk_indexer_destroy(pk_indexer *ix) {
     if (!ix) return;
     hipSetDevice(ix->device);
     if (ix->stream) hipStreamSynchronize(ix->stream);
-    hipFree(ix->table8); hipFree(ix->carry); hipFree(ix->carry0); hipFree(ix->hist); hipFree(ix->hist_rep); hipFree(ix->recs);
+    hipFree(ix->table8); hipFree(ix->tail); hipFree(ix->tail0); hipFree(ix->hist_rep); hipFree(ix->recs);
     if (ix->pin) hipHostFree(ix->pin);
     hipFree(ix->c_l1); hipFree(ix->c_l1s); hipFree(ix->c_l2); hipFree(ix->c_l2s); hipFree(ix->lane_state); hipFree(ix->packs); hipFree(ix->chunk_odd); hipFree(ix->t_l1); hipFree(ix->t_l2); hipFree(ix->staging[0]); hipFree(ix->staging[1]); hipFree(ix->ws);
     for (auto &e : ix->ev) if (e) hipEventDestroy(e);
@@ -294,17 +297,18 @@ extern "C" int pk_indexer_create_slice(pk_indexer **out, int k, int device, int 
     if ((e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     for (auto &ev : ix->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc(&ix->table8, std::max<uint64_t>(ix->n, 16))) != hipSuccess) return bail(e, "hipMalloc(u8 table)");
-    if ((e = hipMalloc(&ix->carry, sizeof(Carry))) != hipSuccess) return bail(e, "hipMalloc(carry)");
-    if ((e = hipMalloc(&ix->carry0, sizeof(Carry))) != hipSuccess) return bail(e, "hipMalloc(carry0)");
+    if ((e = hipMalloc(&ix->tail, sizeof(pk_indexer::Tail))) != hipSuccess) return bail(e, "hipMalloc(carry)");
+    if ((e = hipMalloc(&ix->tail0, sizeof(pk_indexer::Tail))) != hipSuccess) return bail(e, "hipMalloc(carry0)");
+    ix->carry = &ix->tail->carry; ix->hist = ix->tail->hist;
     if ((e = hipHostMalloc(&ix->pin, sizeof(*ix->pin), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
     {
         Carry c;
         memset(&c, 0, sizeof c);
         c.l1 = 8u | 1u | (LS_START << 1);                    // l1_state(LS_START)
         c.l2.flags = F_NONID | F_PRESET | F_BRK;             // l2_state(0, 0, 0, 0)
-        if ((e = hipMemcpy(ix->carry0, &c, sizeof c, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(carry0)");
+        if ((e = hipMemset(ix->tail0, 0, sizeof(pk_indexer::Tail))) != hipSuccess) return bail(e, "hipMemset(carry0)");
+        if ((e = hipMemcpy(&ix->tail0->carry, &c, sizeof c, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(carry0)");
     }
-    if ((e = hipMalloc(&ix->hist, 256 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(hist)");
     if ((e = hipMalloc(&ix->hist_rep, (size_t)HIST_REPLICAS * 256 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(hist replicas)");
     if ((e = hipMemset(ix->hist_rep, 0, (size_t)HIST_REPLICAS * 256 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(hist replicas)");
     {
@@ -425,8 +429,10 @@ static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
             return fail(PK_ERR_HIP, "partition pipeline launch failed: %s", hipGetErrorString(hipGetLastError()));
         HIPCHK(hipEventRecord(ix->ev[9], ix->stream));
         volatile uint32_t *got = ix->pin->flags;
+        // what the host needs of the feed, in two small copies behind the last kernel: the flags, and the stream totals +
+        // value histogram (pk_indexer_finish then has nothing left to fetch)
         HIPCHK(hipMemcpyAsync(ix->pin->flags, flags, sizeof ix->pin->flags, hipMemcpyDeviceToHost, ix->stream));
-        HIPCHK(hipMemcpyAsync(&ix->pin->n_recs, &ix->carry->n_recs, sizeof(uint64_t), hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipMemcpyAsync(&ix->pin->tail, ix->tail, sizeof(pk_indexer::Tail), hipMemcpyDeviceToHost, ix->stream));
         HIPCHK(hipStreamSynchronize(ix->stream));
         HIPCHK(hipGetLastError());
         time_reset(ix);
@@ -434,7 +440,7 @@ static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
         if (attempt >= 3) return fail(PK_ERR_HIP, "the feed's layout did not settle (internal error, flag %u)", got[0]);
         armed = false;
         if (got[0] == 2u) {                                  // more records than the array holds: grow it, squeeze again
-            rc = ensure_recs(ix, ix->pin->n_recs);
+            rc = ensure_recs(ix, ix->pin->tail.carry.n_recs);
             if (rc) return rc;
             squeeze = true;
         } else {                                             // a bucket outgrew its sampled room: lay out again, exactly
@@ -445,7 +451,8 @@ static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
         }
     }
     const uint64_t recs_before = ix->n_recs;
-    ix->n_recs = ix->pin->n_recs;
+    ix->n_recs = ix->pin->tail.carry.n_recs;
+    ix->tail_on_host = true;
     // room for the next feed's records before it arrives: as many again as this feed brought, and then some
     rc = ensure_recs(ix, ix->n_recs + 2 * (ix->n_recs - recs_before) + 1024);
     if (rc) return rc;
@@ -520,30 +527,34 @@ extern "C" int pk_indexer_finish(pk_indexer *ix, uint64_t *num_kmers_out, uint64
     if (!ix) return fail(PK_ERR_ARG, "null indexer");
     HIPCHK(hipSetDevice(ix->device));
     if (!ix->finished) {
-        HIPCHK(hipEventRecord(ix->ev[4], ix->stream));
-        if (ix->table_fresh) {                               // nothing was fed: the table is all zero
-            HIPCHK(hipMemsetAsync(ix->table8, 0, std::max<uint64_t>(ix->n, 16), ix->stream));
-            ix->table_fresh = false;
+        if (ix->tail_on_host && !ix->table_fresh) {
+            // the usual case: the last feed's read-back already holds the totals and the histogram (kept up to date by
+            // k_bucket_count / k_apply_side: no pass over the table), and every kernel has finished -- nothing to do
+            ix->t_final = 0;
+        } else {
+            HIPCHK(hipEventRecord(ix->ev[4], ix->stream));
+            if (ix->table_fresh) {                           // nothing was fed: the table is all zero
+                HIPCHK(hipMemsetAsync(ix->table8, 0, std::max<uint64_t>(ix->n, 16), ix->stream));
+                ix->table_fresh = false;
+            }
+            HIPCHK(hipEventRecord(ix->ev[5], ix->stream));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(&ix->pin->tail, ix->tail, sizeof(pk_indexer::Tail), hipMemcpyDeviceToHost, ix->stream));
+            HIPCHK(hipStreamSynchronize(ix->stream));
+            ix->tail_on_host = true;
+            time_reset(ix);
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, ix->ev[4], ix->ev[5]));
+            ix->t_final = ms * 1e-3;
         }
-        // the value histogram was kept up to date by k_bucket_count / k_apply_side: no pass over the table
-        HIPCHK(hipEventRecord(ix->ev[5], ix->stream));
-        HIPCHK(hipGetLastError());
-        // the totals and the histogram land in pinned memory behind the last kernel: one wait for everything
-        HIPCHK(hipMemcpyAsync(&ix->pin->carry, ix->carry, sizeof(Carry), hipMemcpyDeviceToHost, ix->stream));
-        HIPCHK(hipMemcpyAsync(ix->pin->hist, ix->hist, sizeof ix->pin->hist, hipMemcpyDeviceToHost, ix->stream));
-        HIPCHK(hipStreamSynchronize(ix->stream));
-        time_reset(ix);
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, ix->ev[4], ix->ev[5]));
-        ix->t_final = ms * 1e-3;
         ix->finished = true;
     }
-    const Carry &c = ix->pin->carry;
+    const Carry &c = ix->pin->tail.carry;
     if (num_kmers_out) *num_kmers_out = c.num_kmers;
     if (total_bp_out) *total_bp_out = c.total_bp;
     if (n_recs_out) *n_recs_out = c.n_recs;
     if (hist256_out) {
-        const unsigned long long *h = ix->pin->hist;
+        const unsigned long long *h = ix->pin->tail.hist;
         uint64_t nonzero = 0;
         for (int v = 1; v < 256; v++) { hist256_out[v] = h[v]; nonzero += h[v]; }
         hist256_out[0] = ix->n - nonzero;                // zeros are not tallied on the device
