@@ -66,12 +66,17 @@ __device__ __forceinline__ uint64_t n_words_for(uint64_t n) { return ((n + 2047u
 __device__ __forceinline__ uint4 load_half(const uint8_t *t, uint64_t off, uint64_t n) {
     if (off + 16u <= n) {
         // every byte is read exactly once: stream it past the caches (nontemporal)
+        // (the table pointers come out of a pointer array, so the compiler cannot tell their address space and would emit
+        // FLAT loads, which count on the LDS counter as well and complete out of order: every LDS wait then also drains the
+        // loads in flight.  They are global memory: say so.)
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(t + off));
+        typedef const __attribute__((address_space(1))) u32x4 *gptr;
+        const u32x4 x = __builtin_nontemporal_load((gptr)(t + off));
         return make_uint4(x.x, x.y, x.z, x.w);
     }
     uint32_t v[4] = {0, 0, 0, 0};
-    for (uint64_t i = off; i < n; i++) v[(i - off) >> 2] |= (uint32_t)t[i] << (8u * ((i - off) & 3u));
+    const __attribute__((address_space(1))) uint8_t *tg = (const __attribute__((address_space(1))) uint8_t *)t;
+    for (uint64_t i = off; i < n; i++) v[(i - off) >> 2] |= (uint32_t)tg[i] << (8u * ((i - off) & 3u));
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 __device__ __forceinline__ void load_word(const uint8_t *t, uint64_t w, uint64_t n, uint4 &a, uint4 &b) {
@@ -231,23 +236,40 @@ __device__ __forceinline__ uint32_t planes_ge(const uint32_t (&p)[8], uint32_t t
 }
 
 template <int SLOTS, int TW, int ITEMS, int MAXT>
-__global__ __launch_bounds__(MAXT) void k_gram_mw(const uint8_t *const *__restrict__ tables, int N, uint64_t n, WindowSet ws,
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT == 512 ? 4 : 1, 8))) void k_gram_mw(const uint8_t *const *__restrict__ tables, int N, uint64_t n, WindowSet ws,
                                                  unsigned long long *__restrict__ pair) {
     extern __shared__ uint32_t masks[];                 // [W][NBT][TW]
     constexpr bool PACK = SLOTS > 1;
+    constexpr int RMAX = TW / 64;                        // 64-word rounds per tile
     const int NBT = ((N + BLK - 1) / BLK) * BLK;
     const int nthreads = blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NB = NBT / BLK, n_pb = NB * (NB + 1) / 2;  // pair blocks (a, b), a <= b, row by row
-    int bi[SLOTS], bj[SLOTS], win[SLOTS];
+    // A wave's slot is a (window, pair block) combination -- or, when there are fewer combinations than wave slots (few
+    // windows), one ROUND of 64 words of a combination, so that the tallies of a tile are spread over all waves instead of
+    // running as one long chain on a few of them (a 2-window sweep at N = 13 kept 3 of 12 waves busy in this phase).
+    const int combos = ws.W * n_pb, n_waves = nthreads / 64;
+    const int rs = (RMAX > 1 && combos * RMAX <= n_waves * SLOTS) ? RMAX : 1;      // rounds a combination is split into
+    int bi[SLOTS], bj[SLOTS], win[SLOTS], r_lo[SLOTS], r_hi[SLOTS];
+    uint32_t pm_lo[SLOTS], pm_hi[SLOTS];                 // which of the slot's 8 x 8 pairs exist (bit i * 8 + j; packed: pairs (2j, 2j+1) share bit i * 8 + 2j)
 #pragma unroll
     for (int s = 0; s < SLOTS; s++) {
-        const int c = wave * SLOTS + s;                  // combination = (window, pair block)
-        const bool on = c < ws.W * n_pb;
+        const int u = wave * SLOTS + s;                  // work unit
+        const int c = u / rs;                            // combination = (window, pair block)
+        const bool on = c < combos;
         int a = 0, rem = c % n_pb;
         while (rem >= NB - a) { rem -= NB - a; a++; }
+        const int ni = min(BLK, N - a * BLK), nj = min(BLK, N - (a + rem) * BLK);
+        unsigned long long pm = 0;
+        for (int i = 0; i < ni; i++)
+            for (int j = 0; j < nj; j++)
+                if (rem != 0 || j >= i) pm |= 1ull << (i * 8 + (PACK ? (j & ~1) : j));   // a diagonal block keeps its upper triangle
         win[s] = __builtin_amdgcn_readfirstlane(on ? c / n_pb : -1);     // wave-uniform: in scalar registers
         bi[s] = __builtin_amdgcn_readfirstlane(on ? a : -1);
         bj[s] = __builtin_amdgcn_readfirstlane(on ? a + rem : -1);
+        r_lo[s] = __builtin_amdgcn_readfirstlane(rs > 1 ? u % rs : 0);
+        r_hi[s] = __builtin_amdgcn_readfirstlane(rs > 1 ? u % rs + 1 : RMAX);
+        pm_lo[s] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pm);
+        pm_hi[s] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pm >> 32));
     }
     constexpr int AJ = PACK ? BLK / 2 : BLK;
     uint32_t acc[SLOTS][BLK][AJ];
@@ -261,21 +283,38 @@ __global__ __launch_bounds__(MAXT) void k_gram_mw(const uint8_t *const *__restri
     const uint64_t n_words = n_words_for(n);
     const uint64_t n_tiles = (n_words + TW - 1) / TW;
     const int items = NBT * TW;
+    // item m of this thread: table t_m (wave-uniform) and the word w_m of the tile -- both the same in every tile, and so is
+    // the byte offset of the word inside the tile's 2 KiB blocks: a tile that lies wholly inside the tables is fetched
+    // with a scalar base (table pointer + tile offset) and that constant lane offset, no per-lane address arithmetic
+    // (the launcher's thread counts are multiples of TW, so the word -- and the offset -- is the same for all of a thread's items)
+    const uint32_t w_mine = threadIdx.x % TW;
+    const uint32_t voff = (w_mine >> 6) * 2048u + (w_mine & 63u) * 16u;
     uint4 ra[ITEMS], rb[ITEMS];
     auto fetch_item = [&](uint64_t tile, int m) {
-        const uint64_t w0 = tile * TW;
         const int q = threadIdx.x + m * nthreads;
-        const int t = __builtin_amdgcn_readfirstlane(q / TW), w = q % TW;
+        const int t = __builtin_amdgcn_readfirstlane(q / TW);
         ra[m] = make_uint4(0, 0, 0, 0); rb[m] = ra[m];
-        if (q < items && t < N && w0 + w < n_words && tile < n_tiles) load_word(tables[t], w0 + w, n, ra[m], rb[m]);
+        if (q >= items || t >= N || tile >= n_tiles) return;
+        const uint64_t byte0 = tile * (uint64_t)(RMAX * 2048);            // uniform
+        if (byte0 + (uint64_t)(RMAX * 2048) <= n) {                        // uniform: nearly every tile
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(1))) u32x4 *gptr;   // global, not flat: see load_half
+            const uint8_t *base = tables[t] + byte0;
+            const u32x4 x = __builtin_nontemporal_load((gptr)(base + voff));
+            const u32x4 y = __builtin_nontemporal_load((gptr)(base + voff + 1024u));
+            ra[m] = make_uint4(x.x, x.y, x.z, x.w); rb[m] = make_uint4(y.x, y.y, y.z, y.w);
+        } else {
+            const uint64_t w0 = tile * TW;
+            const int w = q % TW;
+            if (w0 + w < n_words) load_word(tables[t], w0 + w, n, ra[m], rb[m]);
+        }
     };
 #pragma unroll
     for (int m = 0; m < ITEMS; m++) fetch_item(blockIdx.x, m);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         // phase 1: the tile's (table, word) items -> one mask per window in LDS.  An item's registers are free as soon as
         // its bit planes exist, so the SAME item of the next tile is requested right there: a whole iteration (the rest
-        // of this phase, both barriers and the tallies) covers its latency, with no second set of registers.  (Requested
-        // only after the first barrier, a 2-window sweep at N = 13 ran at 2.6 TB/s: nothing but latency.)
+        // of this phase, both barriers and the tallies) covers its latency, with no second set of registers.
 #pragma unroll
         for (int m = 0; m < ITEMS; m++) {
             const int q = threadIdx.x + m * nthreads;
@@ -296,30 +335,34 @@ __global__ __launch_bounds__(MAXT) void k_gram_mw(const uint8_t *const *__restri
             }
         }
         __syncthreads();
-        // phase 2: every wave tallies its (window, 8x8 pair block) slots over the tile's words.  Only pairs that exist are
-        // tallied: rows / columns past the last table and, in a diagonal block, the lower triangle are skipped by uniform
-        // branches (N = 13: 91 of the 192 pair slots of its three blocks) -- this phase is vector-issue bound.
+        // phase 2: every wave tallies its slots over the tile's words.  Only pairs that exist are tallied: rows / columns
+        // past the last table and, in a diagonal block, the lower triangle are skipped -- one scalar bit test per pair on
+        // the slot's pair mask (N = 13: 91 of the 192 pair slots of its three blocks).  This phase is vector-issue bound.
 #pragma unroll
         for (int s = 0; s < SLOTS; s++) {
             if (bi[s] < 0) continue;
             const uint32_t *mi = masks + win[s] * items + bi[s] * BLK * TW, *mj = masks + win[s] * items + bj[s] * BLK * TW;
-            const int ni = min(BLK, N - bi[s] * BLK), nj = min(BLK, N - bj[s] * BLK);
-            const bool diag = bi[s] == bj[s];
+            // opaque per tile: otherwise the 64 bit tests of the slot are hoisted out of the tile loop as 64 lane masks in
+            // scalar registers, which spill (140 scalar spills, read back lane by lane inside the loop)
+            uint32_t plo = pm_lo[s], phi = pm_hi[s];
+            asm volatile("" : "+s"(plo), "+s"(phi));
 #pragma unroll
-            for (int r = 0; r < TW / 64; r++) {
+            for (int r = 0; r < RMAX; r++) {
+                if (r < r_lo[s] || r >= r_hi[s]) continue;                 // uniform: this unit's rounds
                 uint32_t a[BLK], b[BLK];
 #pragma unroll
                 for (int i = 0; i < BLK; i++) { a[i] = mi[i * TW + r * 64 + lane]; b[i] = mj[i * TW + r * 64 + lane]; }
 #pragma unroll
                 for (int i = 0; i < BLK; i++) {
-                    if (i >= ni) continue;
+                    const uint32_t row = ((i < 4 ? plo : phi) >> (8 * (i & 3))) & 0xffu;   // scalar
+                    if (row == 0u) continue;
 #pragma unroll
                     for (int j = 0; j < AJ; j++) {
                         if (PACK) {
-                            if (2 * j >= nj || (diag && 2 * j + 1 < i)) continue;
+                            if (!((row >> (2 * j)) & 1u)) continue;
                             acc[s][i][j] += (uint32_t)__builtin_popcount(a[i] & b[2 * j]) + ((uint32_t)__builtin_popcount(a[i] & b[2 * j + 1]) << 16);
                         } else {
-                            if (j >= nj || (diag && j < i)) continue;
+                            if (!((row >> j) & 1u)) continue;
                             acc[s][i][j] += __builtin_popcount(a[i] & b[j]);
                         }
                     }
@@ -386,6 +429,7 @@ int launch_gram_windows(const uint8_t *const *dev_tables, int N, uint64_t n_slic
     //   N <= 24   6 pair blocks x 5 windows: 16 waves x 2 slots,                        tile of 64 words
     //   N <= 32  10 pair blocks x 3 windows: 16 waves x 2 slots,                        tile of 64 words
     const int NBT = NB * BLK;
+    static_assert(512 % 128 == 0 && 768 % 128 == 0 && 1024 % 64 == 0, "k_gram_mw: thread counts are multiples of the tile width");
     if (N <= 8) {
         hipLaunchKernelGGL((k_gram_mw<1, 128, 2, 512>), dim3(grid_for(128, false)), dim3(512), (size_t)W * NBT * 128 * 4, s, dev_tables, N, n_slice, ws, dev_pair);
     } else if (N <= 16) {
