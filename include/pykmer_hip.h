@@ -154,6 +154,18 @@ int pk_gram_device_accumulate_windows(const void *const *dev_tables, int N, uint
                                       double *kernel_seconds_out);
 int pk_gram_expand(const uint64_t *pair, int N, uint64_t *matrix_out);
 
+/* ---- BGZF on the host (no device work): the reference reads `.kin.bgz` tables and `.fa.gz` / `.bgz` inputs through one
+ * Python gzip.open stream (tools.py:294-305, indexer.py:112-115); bgzip output (README.md:26) is a series of independent
+ * gzip members, inflated here block-parallel on native threads straight into the caller's buffer.
+ * pk_bgzf_scan: walks the member headers of `src` (no inflation): offset, size and ISIZE of each; PK_ERR_ARG if the
+ * bytes are not BGZF; PK_ERR_RECS_CAP if more than `cap` blocks (*n_blocks_out = the count; call again with room).
+ * pk_bgzf_inflate: block i (c_off[i], c_size[i]) -> dst + u_off[i], u_off[i + 1] - u_off[i] bytes (u_off has n_blocks + 1
+ * entries); CRC32 and ISIZE of every block are checked (SAM spec 4.1). */
+int pk_bgzf_scan(const uint8_t *src, uint64_t n_bytes, uint64_t cap, uint64_t *c_off_out, uint64_t *c_size_out,
+                 uint64_t *isize_out, uint64_t *n_blocks_out);
+int pk_bgzf_inflate(const uint8_t *src, const uint64_t *c_off, const uint64_t *c_size, const uint64_t *u_off,
+                    uint64_t n_blocks, uint8_t *dst, int threads);
+
 /* ---- diagnostics (tools/, tests/): no reference counterpart, no effect on any result.
  * pk_diag_occupancy: workgroups per CU the runtime grants kernel `which` (0 k_bucket_count_half, 1 k_bucket_count_bytes,
  * 2 k_bucket_count_half_lean, 3 k_scatter2<claim>); negative = HIP error.

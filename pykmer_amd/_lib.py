@@ -52,6 +52,8 @@ _SIGNATURES = {
     "pk_gram_device_accumulate_windows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
                                                           ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "pk_gram_expand": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "pk_bgzf_scan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _u64p]),
+    "pk_bgzf_inflate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int]),
     "pk_diag_occupancy": (ctypes.c_int, [ctypes.c_int]),
     "pk_diag_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p]),
 }
@@ -294,6 +296,31 @@ def gram_device_accumulate_windows(dev_ptrs, n_slice: int, dev_pair_accum: int, 
     _check(load().pk_gram_device_accumulate_windows(ptrs, N, n_slice, mins, maxs, W, ctypes.c_void_p(dev_pair_accum), device,
                                                     ctypes.byref(secs)))
     return secs.value
+
+
+def bgzf_scan(buf: np.ndarray):
+    """pk_bgzf_scan: (offsets, sizes, isizes) of every BGZF block in a u8 array (int64 arrays); ValueError if not BGZF."""
+    cap = max(16, buf.size // 4096)
+    while True:
+        c_off, c_size, isize = (np.zeros(cap, dtype=np.uint64) for _ in range(3))
+        n = ctypes.c_uint64(0)
+        rc = load().pk_bgzf_scan(buf.ctypes.data, buf.size, cap, c_off.ctypes.data, c_size.ctypes.data, isize.ctypes.data, ctypes.byref(n))
+        if rc == PK_ERR_RECS_CAP:
+            cap = int(n.value)
+            continue
+        _check(rc)
+        k = int(n.value)
+        return c_off[:k].astype(np.int64), c_size[:k].astype(np.int64), isize[:k].astype(np.int64)
+
+
+def bgzf_inflate(buf: np.ndarray, c_off, c_size, u_off, out: np.ndarray, threads: int) -> None:
+    """pk_bgzf_inflate: blocks (c_off[i], c_size[i]) of `buf` -> out[u_off[i] - u_off[0] : u_off[i + 1] - u_off[0]]."""
+    n = len(c_off)
+    co = np.ascontiguousarray(c_off, dtype=np.uint64)
+    cs = np.ascontiguousarray(c_size, dtype=np.uint64)
+    uo = np.ascontiguousarray(np.asarray(u_off, dtype=np.int64) - int(u_off[0]), dtype=np.uint64)
+    assert uo.size == n + 1 and out.dtype == np.uint8 and out.flags.c_contiguous and out.size >= int(uo[-1])
+    _check(load().pk_bgzf_inflate(buf.ctypes.data, co.ctypes.data, cs.ctypes.data, uo.ctypes.data, n, out.ctypes.data, int(threads)))
 
 
 def diag_plan(k: int, n_bytes: int = 0) -> dict:

@@ -4,7 +4,9 @@ The reference compresses finished tables with the htslib CLI (`bgzip -i -I $F.bg
 README.md:26, data/README.md:24) and reads them back through one single-threaded `gzip.open`
 (tools.py:294-305).  A BGZF file is a series of independent gzip members of <= 64 KiB each carrying
 their compressed size in a `BC` extra field (SAM spec 4.1), so both directions parallelise over
-blocks; zlib releases the GIL, so plain threads are enough.  The `.gzi` index is the layout
+blocks.  Reading goes through the library (pk_bgzf_scan / pk_bgzf_inflate, csrc/bgzf_host.cpp: zlib on native threads
+straight into the destination array -- from Python threads the per-block interpreter work capped a 1 GiB table at ~1 GB/s);
+the writer deflates on Python threads (zlib releases the GIL).  The `.gzi` index is the layout
 gzireader.py:12-34 prints: u64 count, then (compressed_offset, uncompressed_offset) u64 pairs for
 every block but the first.
 
@@ -23,7 +25,8 @@ import numpy as np
 BLOCK_INPUT = 0xFF00                    # uncompressed bytes per block (htslib BGZF_BLOCK_SIZE)
 _HEADER = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00"
 EOF_BLOCK = _HEADER + struct.pack("<H", 27) + b"\x03\x00" + struct.pack("<II", 0, 0)
-DEFAULT_THREADS = max(1, min(16, os.cpu_count() or 1))
+DEFAULT_THREADS = max(1, min(16, os.cpu_count() or 1))          # deflate (Python threads)
+INFLATE_THREADS = max(1, min(64, len(os.sched_getaffinity(0))))  # inflate (native threads)
 
 
 def _deflate_block(data: bytes, level: int) -> bytes:
@@ -95,31 +98,22 @@ def scan_blocks(buf) -> List[Tuple[int, int]]:
     return blocks
 
 
-def _inflate_block(buf, off: int, size: int, out, out_off: int) -> None:
-    xlen = struct.unpack_from("<H", buf, off + 10)[0]
-    body = buf[off + 12 + xlen: off + size - 8]
-    crc, isize = struct.unpack_from("<II", buf, off + size - 8)
-    data = zlib.decompress(body, -15, isize) if isize else b""
-    if len(data) != isize or zlib.crc32(data) != crc:
-        raise OSError(f"BGZF block at {off}: CRC / size mismatch")
-    out[out_off: out_off + isize] = np.frombuffer(data, dtype=np.uint8)
+def _native():
+    from . import _lib
+    return _lib
 
 
-def decompress_file(path: str, expected_size: int = None, threads: int = DEFAULT_THREADS) -> np.ndarray:
+def decompress_file(path: str, expected_size: int = None, threads: int = None) -> np.ndarray:
     """Whole file -> uint8 array.  BGZF blocks are inflated in parallel straight into the result; any
     other gzip stream goes through gzip.open like tools.py:300-302."""
-    raw = np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, np.uint8)
-    buf = memoryview(raw)
-    blocks = scan_blocks(buf)
-    if not blocks:
+    if os.path.getsize(path) and is_bgzf(path):
+        c_offs, c_sizes, u_offs = block_index(path)
+        raw = np.memmap(path, dtype=np.uint8, mode="r")
+        data = np.empty(int(u_offs[-1]), dtype=np.uint8)
+        _native().bgzf_inflate(raw, c_offs, c_sizes, u_offs, data, threads or INFLATE_THREADS)
+    else:
         with gzip.open(path, "rb") as fh:
             data = np.frombuffer(fh.read(), dtype=np.uint8)
-    else:
-        sizes = [struct.unpack_from("<I", buf, off + size - 4)[0] for off, size in blocks]
-        offs = np.concatenate(([0], np.cumsum(sizes, dtype=np.int64)))
-        data = np.empty(int(offs[-1]), dtype=np.uint8)
-        with ThreadPoolExecutor(max_workers=threads) as pool:
-            list(pool.map(lambda i: _inflate_block(buf, blocks[i][0], blocks[i][1], data, int(offs[i])), range(len(blocks))))
     if expected_size is not None and data.size != expected_size:
         raise AssertionError(f"{path}: {data.size} bytes after inflating, expected {expected_size}")
     return data
@@ -151,12 +145,10 @@ def block_index(path: str):
         last_isize = struct.unpack_from("<I", buf, last + last_size - 4)[0]
         u_offs = np.append(u_offs, u_offs[-1] + last_isize)
     else:
-        blocks = scan_blocks(buf)
-        if not blocks:
-            raise OSError(f"{path}: not a BGZF file")
-        c_offs = np.array([o for o, _ in blocks], dtype=np.int64)
-        c_sizes = np.array([z for _, z in blocks], dtype=np.int64)
-        isizes = np.array([struct.unpack_from("<I", buf, o + z - 4)[0] for o, z in blocks], dtype=np.int64)
+        try:
+            c_offs, c_sizes, isizes = _native().bgzf_scan(raw)
+        except ValueError as exc:
+            raise OSError(f"{path}: {exc}") from None
         keep = isizes > 0                                    # the empty end-of-file block (and any other empty block) is no data
         if keep.any():
             c_offs, c_sizes, isizes = c_offs[keep], c_sizes[keep], isizes[keep]
@@ -169,7 +161,7 @@ def block_index(path: str):
     return _INDEX_CACHE[key]
 
 
-def decompress_range(path: str, lo: int, hi: int, threads: int = DEFAULT_THREADS) -> Tuple[np.ndarray, int]:
+def decompress_range(path: str, lo: int, hi: int, threads: int = None) -> Tuple[np.ndarray, int]:
     """Uncompressed bytes [lo, hi) of a gzip / BGZF file -> (array, bytes inflated to get them).
 
     BGZF: the blocks overlapping the range are found in the (cached) block index -- the `.gzi` beside the file, or one
@@ -193,22 +185,20 @@ def decompress_range(path: str, lo: int, hi: int, threads: int = DEFAULT_THREADS
     first = int(np.searchsorted(u_offs, lo, side="right")) - 1
     end = int(np.searchsorted(u_offs, hi, side="left"))       # blocks [first, end) overlap [lo, hi)
     raw = np.memmap(path, dtype=np.uint8, mode="r")
-    buf = memoryview(raw)
     base = int(u_offs[first])
     span = np.empty(int(u_offs[end]) - base, dtype=np.uint8)
-    with ThreadPoolExecutor(max_workers=threads) as pool:
-        list(pool.map(lambda i: _inflate_block(buf, int(c_offs[i]), int(c_sizes[i]), span, int(u_offs[i]) - base), range(first, end)))
+    _native().bgzf_inflate(raw, c_offs[first:end], c_sizes[first:end], u_offs[first:end + 1], span, threads or INFLATE_THREADS)
     return span[lo - base: hi - base], int(span.size)
 
 
-def iter_pieces(path: str, piece_bytes: int, threads: int = DEFAULT_THREADS):
+def iter_pieces(path: str, piece_bytes: int, threads: int = None):
     """The inflated stream of a BGZF file in pieces of about `piece_bytes` (whole blocks), in order.  Piece i + 1 is
-    inflated (block-parallel, on `threads` host threads) while the caller still works on piece i -- the indexer feeds
-    piece i to the GPU meanwhile -- so a bgzipped FASTA never sits inflated in host memory as a whole."""
+    inflated (block-parallel, native threads) while the caller still works on piece i -- the indexer feeds piece i to the
+    GPU meanwhile -- so a bgzipped FASTA never sits inflated in host memory as a whole."""
+    import threading
     c_offs, c_sizes, u_offs = block_index(path)
     n_blocks = len(c_offs)
     raw = np.memmap(path, dtype=np.uint8, mode="r")
-    buf = memoryview(raw)
     cuts, i = [], 0
     while i < n_blocks:
         j = int(np.searchsorted(u_offs, u_offs[i] + piece_bytes, side="right")) - 1
@@ -216,21 +206,29 @@ def iter_pieces(path: str, piece_bytes: int, threads: int = DEFAULT_THREADS):
         cuts.append((i, j))
         i = j
 
-    def inflate(cut, pool):
+    def start(cut):
         i, j = cut
-        base = int(u_offs[i])
-        out = np.empty(int(u_offs[j]) - base, dtype=np.uint8)
-        return out, [pool.submit(_inflate_block, buf, int(c_offs[b]), int(c_sizes[b]), out, int(u_offs[b]) - base) for b in range(i, j)]
+        out = np.empty(int(u_offs[j] - u_offs[i]), dtype=np.uint8)
+        box = {}
 
-    with ThreadPoolExecutor(max_workers=threads) as pool:
-        ahead = inflate(cuts[0], pool) if cuts else None
-        for n in range(len(cuts)):
-            out, futures = ahead
-            for f in futures:
-                f.result()
-            ahead = inflate(cuts[n + 1], pool) if n + 1 < len(cuts) else None   # runs while the caller holds `out`
-            if out.size:
-                yield out
+        def run():
+            try:
+                _native().bgzf_inflate(raw, c_offs[i:j], c_sizes[i:j], u_offs[i:j + 1], out, threads or INFLATE_THREADS)
+            except BaseException as exc:                    # re-raised by the consumer
+                box["exc"] = exc
+        t = threading.Thread(target=run, daemon=True)
+        t.start()
+        return out, t, box
+
+    ahead = start(cuts[0]) if cuts else None
+    for n in range(len(cuts)):
+        out, t, box = ahead
+        t.join()
+        if "exc" in box:
+            raise box["exc"]
+        ahead = start(cuts[n + 1]) if n + 1 < len(cuts) else None       # runs while the caller holds `out`
+        if out.size:
+            yield out
 
 
 def is_bgzf(path: str) -> bool:

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libpykmer_hip.so")
-SOURCES = ["kmer_count.hip", "kmer_pack.hip", "kmer_fuse.hip", "kmer_part.hip", "gram_scan.hip", "pk_api.hip"]
+SOURCES = ["kmer_count.hip", "kmer_pack.hip", "kmer_fuse.hip", "kmer_part.hip", "gram_scan.hip", "pk_api.hip", "bgzf_host.cpp"]   # the .cpp is host-only (zlib)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 
 
@@ -25,7 +25,7 @@ def _headers():
 
 
 def _deps():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + _headers()
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp"))) + _headers()
 
 
 def _stale() -> bool:
@@ -47,10 +47,10 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
         force = True
 
     def compile_one(src: str) -> str:
-        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         path = os.path.join(CSRC, src)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(newest_header, os.path.getmtime(path)):
-            cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+            cmd = ([hipcc] + flags if src.endswith(".hip") else [hipcc, "-O3", "-std=c++17", "-fPIC"]) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd, cwd=CSRC)
@@ -60,7 +60,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
         objs = list(pool.map(compile_one, SOURCES))
     with open(tag, "w") as fh:
         fh.write(" ".join(flags))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lz", "-lpthread", "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd, cwd=CSRC)

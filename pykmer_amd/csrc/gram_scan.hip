@@ -290,23 +290,31 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT == 51
     const uint32_t w_mine = threadIdx.x % TW;
     const uint32_t voff = (w_mine >> 6) * 2048u + (w_mine & 63u) * 16u;
     uint4 ra[ITEMS], rb[ITEMS];
-    auto fetch_item = [&](uint64_t tile, int m) {
+    // the items' table pointers, read once (scalar loads share the LDS counter: fetched inside the loop, each one would
+    // wait for the mask stores in flight)
+    const uint8_t *tab[ITEMS];
+#pragma unroll
+    for (int m = 0; m < ITEMS; m++) {
         const int q = threadIdx.x + m * nthreads;
         const int t = __builtin_amdgcn_readfirstlane(q / TW);
+        tab[m] = t < N ? tables[t] : nullptr;                  // t < N implies q < items; all of it wave-uniform
+    }
+    auto fetch_item = [&](uint64_t tile, int m) {
+        const int q = threadIdx.x + m * nthreads;
         ra[m] = make_uint4(0, 0, 0, 0); rb[m] = ra[m];
-        if (q >= items || t >= N || tile >= n_tiles) return;
+        if (tab[m] == nullptr || tile >= n_tiles) return;                  // uniform
         const uint64_t byte0 = tile * (uint64_t)(RMAX * 2048);            // uniform
         if (byte0 + (uint64_t)(RMAX * 2048) <= n) {                        // uniform: nearly every tile
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
             typedef const __attribute__((address_space(1))) u32x4 *gptr;   // global, not flat: see load_half
-            const uint8_t *base = tables[t] + byte0;
+            const uint8_t *base = tab[m] + byte0;
             const u32x4 x = __builtin_nontemporal_load((gptr)(base + voff));
             const u32x4 y = __builtin_nontemporal_load((gptr)(base + voff + 1024u));
             ra[m] = make_uint4(x.x, x.y, x.z, x.w); rb[m] = make_uint4(y.x, y.y, y.z, y.w);
         } else {
             const uint64_t w0 = tile * TW;
             const int w = q % TW;
-            if (w0 + w < n_words) load_word(tables[t], w0 + w, n, ra[m], rb[m]);
+            if (w0 + w < n_words) load_word(tab[m], w0 + w, n, ra[m], rb[m]);
         }
     };
 #pragma unroll

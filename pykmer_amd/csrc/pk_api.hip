@@ -27,6 +27,8 @@ static int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+namespace pk { int set_error(int code, const std::string &msg) { g_err = msg; return code; } }   // for the other translation units
+
 #define HIPCHK(expr)                                                                                          \
     do {                                                                                                      \
         hipError_t _e = (expr);                                                                               \

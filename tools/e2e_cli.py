@@ -18,6 +18,22 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("PK_TMP", "/tmp")) as d:
     out["indexer_cli_k15_800Mbp_bp_per_s"] = bp / out["indexer_cli_k15_800Mbp_s"]
     meta = json.load(open(big + ".15.kin.json"))
     out["indexer_json_creation_speed"] = meta["creation_speed"]
+    # the same genome bgzipped (what `bgzip genome.fa` writes; indexer.py:112-115 reads .gz / .bgz through gzip.open) and as a
+    # plain gzip stream: inflated in pieces while the GPU counts the piece before
+    from pykmer_amd import bgzf
+    gz = os.path.join(d, "genome_bgzf.fa.gz")
+    t0 = time.perf_counter(); bgzf.compress_file(big, gz, level=1, threads=16, index=False); out["bgzf_level1_fasta_16thr_s"] = time.perf_counter() - t0
+    out["indexer_cli_k15_800Mbp_bgzf_s"] = run(os.path.join(ROOT, "indexer.py"), gz, "genome", "15")
+    out["indexer_cli_bgzf_over_plain"] = out["indexer_cli_k15_800Mbp_bgzf_s"] / out["indexer_cli_k15_800Mbp_s"]
+    assert json.load(open(gz + ".15.kin.json"))["output_file_cheksum"] == meta["output_file_cheksum"]
+    os.remove(gz + ".15.kin")
+    import gzip, shutil
+    pgz = os.path.join(d, "genome_plain.fa.gz")
+    with open(big, "rb") as fi, gzip.open(pgz, "wb", compresslevel=1) as fo:
+        shutil.copyfileobj(fi, fo, 1 << 24)
+    out["indexer_cli_k15_800Mbp_gzip_s"] = run(os.path.join(ROOT, "indexer.py"), pgz, "genome", "15")
+    assert json.load(open(pgz + ".15.kin.json"))["output_file_cheksum"] == meta["output_file_cheksum"]
+    os.remove(pgz + ".15.kin"); os.remove(gz); os.remove(pgz)
     kins = []
     t_idx = 0.0
     for i in range(13):
