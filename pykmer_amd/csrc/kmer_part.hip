@@ -224,7 +224,8 @@ __global__ __launch_bounds__(1024) void k_starts2(uint32_t n_final, const uint32
 // `pos` (wg2_start + B1 + 1) is the running item count over the buckets in that order (k_level1_finish).
 // NT threads x PER records = one tile.  The CLAIM launch runs as 512 x 32: two workgroups share a CU (72 KiB of LDS and
 // 128 registers each), so one sorts while the other waits at a barrier or for its stores.
-template <bool CLAIM, int NT, int PER>
+// REC24: the level-1 records are 3-byte records in two planes (32-bit k-mers; part_common.h), `in` is the 16-bit plane.
+template <bool CLAIM, int NT, int PER, bool REC24 = false>
 __global__ __launch_bounds__(NT, 4) void k_scatter2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ wg2_start,
                                                    const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ bucket_end,
                                                    const uint32_t *__restrict__ rowoff, const uint32_t *__restrict__ final_start, PartPlan pl,
@@ -240,14 +241,24 @@ __global__ __launch_bounds__(NT, 4) void k_scatter2(const uint32_t *__restrict__
     // records [lo, hi) of level-1 bucket b: 16-byte aligned windows of TILE records, the first / last partly masked.
     // The next window's loads are issued before the current tile is sorted, so they fly during its barriers.
     typedef uint32_t Quad __attribute__((ext_vector_type(4)));
+    typedef uint32_t Pair __attribute__((ext_vector_type(2)));
+    const uint16_t *in_lo = reinterpret_cast<const uint16_t *>(in);
+    const uint8_t *in_hi = reinterpret_cast<const uint8_t *>(in) + level1_hi_plane_offset(pl.capacity1);
     auto item = [&](uint32_t b, uint32_t lo, uint32_t hi) {
+        // four records per lane and load: 16 bytes of 4-byte records, or 8 bytes of the low plane + 4 of the high plane
+        // (x, y: the low halves of records 0-1 and 2-3; z: the four high bytes)
         auto fetch = [&](uint32_t win, Quad (&v)[PER / 4]) {
             const uint32_t v_hi = min(hi, win + (uint32_t)TILE);
 #pragma unroll
             for (int j = 0; j < PER / 4; j++) {
                 const uint32_t i = win + (threadIdx.x + j * NT) * 4u;
                 v[j] = Quad{0u, 0u, 0u, 0u};
-                if (i < v_hi) v[j] = *reinterpret_cast<const Quad *>(in + i);
+                if (i < v_hi) {
+                    if (REC24) {
+                        const Pair l = *reinterpret_cast<const Pair *>(in_lo + i);
+                        v[j] = Quad{l.x, l.y, *reinterpret_cast<const uint32_t *>(in_hi + i), 0u};
+                    } else v[j] = *reinterpret_cast<const Quad *>(in + i);
+                }
             }
         };
         Quad nxt[PER / 4];
@@ -263,7 +274,14 @@ __global__ __launch_bounds__(NT, 4) void k_scatter2(const uint32_t *__restrict__
             const uint32_t n_tile = v_hi - v_lo;
             uint32_t r[PER];
 #pragma unroll
-            for (int j = 0; j < PER / 4; j++) { r[j * 4] = nxt[j].x; r[j * 4 + 1] = nxt[j].y; r[j * 4 + 2] = nxt[j].z; r[j * 4 + 3] = nxt[j].w; }
+            for (int j = 0; j < PER / 4; j++) {
+                if (REC24) {                                             // record e = low half e | high byte e << 16: one byte permute each
+                    r[j * 4] = __builtin_amdgcn_perm(nxt[j].z, nxt[j].x, 0x0c040100u);
+                    r[j * 4 + 1] = __builtin_amdgcn_perm(nxt[j].z, nxt[j].x, 0x0c050302u);
+                    r[j * 4 + 2] = __builtin_amdgcn_perm(nxt[j].z, nxt[j].y, 0x0c060100u);
+                    r[j * 4 + 3] = __builtin_amdgcn_perm(nxt[j].z, nxt[j].y, 0x0c070302u);
+                } else { r[j * 4] = nxt[j].x; r[j * 4 + 1] = nxt[j].y; r[j * 4 + 2] = nxt[j].z; r[j * 4 + 3] = nxt[j].w; }
+            }
             const bool full = v_lo == win && n_tile == (uint32_t)TILE;   // uniform; nearly every tile: items start 16-byte aligned
             uint32_t okm = 0;
             if (!full) {
@@ -858,7 +876,11 @@ size_t part_workspace_bytes(const PartPlan &pl, uint64_t n_bytes, PartWorkspace 
     lay->final_start = o; o += up((size_t)(nfb + 1) * 4);
     lay->cursor2 = o; o += up((size_t)(nfb + 1) * 4);
     lay->cap2_end = o; o += up((size_t)(nfb + 1) * 4);
-    lay->out1 = o; o += up((size_t)(pl.capacity1 + TILE + 64) * (pl.b2 ? 4 : 2));      // buckets + the dump area
+    // level-1 buckets + the dump tile: 2-byte records when level 1 is the only level, two planes of 2 + 1 bytes for 32-bit
+    // k-mers with a second level (part_common.h), 4-byte records (the low 32 bits) for 64-bit k-mers
+    lay->out1 = o; o += !pl.b2 ? up((size_t)(pl.capacity1 + TILE + 64) * 2)
+                     : pl.k <= 15 ? level1_hi_plane_offset(pl.capacity1) + up((size_t)(pl.capacity1 + TILE + 64))
+                                  : up((size_t)(pl.capacity1 + TILE + 64) * 4);
     lay->hist2 = o; o += up(laid_out2 ? 256 : (size_t)pl.n_wg2_max * pl.B2 * 4);          // per-workgroup digit counts: only without claims
     lay->rowoff2 = o; o += up(laid_out2 ? 256 : (size_t)pl.n_wg2_max * pl.B2 * 4);
     lay->out2 = o; o += up(!pl.b2 ? 256 : laid_out2 ? (size_t)(pl.capacity2 + TILE + 64) * 2 : (size_t)(n_bytes + 64) * 2);
@@ -872,6 +894,7 @@ void part_set_attributes() {
     fuse_set_attributes();
     hipFuncSetAttribute((const void *)k_scatter2<false, SC_T, SC_PER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_scatter2<true, 512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
+    hipFuncSetAttribute((const void *)k_scatter2<true, 512, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_NARROW);
     hipFuncSetAttribute((const void *)k_bucket_count<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute((const void *)k_bucket_count_half<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute((const void *)k_bucket_count_half_lean<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -916,6 +939,7 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
     const uint32_t nfb = pl.B1 * pl.B2;
     const bool laid_out2 = pl.n_tally > pl.B1 || pl.sample2;
     if (pl.B1 > (pl.k <= 15 ? 128u : 512u) || pl.B2 > 512u || pl.fb_bits > 16u) return -3;   // what the kernels' LDS arrays are sized for
+    if (pl.k <= 15 && pl.b2 && (!laid_out2 || pl.addr_bits - pl.b1 > 24u)) return -3;           // 3-byte level-1 records: only the claiming level 2 reads them
     if (!armed && hipMemsetAsync(side_n, 0, PART_FLAG_WORDS * 4, s) != hipSuccess) return -2;   // side-list length + flags
     launch_provision(codes, restarts, n_bases, st2, pl, stride, tally_rows, tally_tot, bucket_base, cursor1, cap_end, final_start, cursor2, cap2_end,
                      flags, s);
@@ -946,9 +970,14 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
         // do not hide each other (both live on the LDS pipe).
         static const uint32_t grid2_env = getenv("PK_GRID2") ? (uint32_t)atoi(getenv("PK_GRID2")) : 4096u;
         const uint32_t grid2 = grid2_env < 8u ? 8u : (grid2_env & ~7u);    // a multiple of 8: every XCD class gets the same number of workgroups
-        hipLaunchKernelGGL((k_scatter2<true, 512, 32>), dim3(grid2), dim3(512), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
-                           bucket_base, bucket_end, (const uint32_t *)nullptr, final_start, pl, out2, cursor2, (const uint32_t *)cap2_end,
-                           (uint32_t)pl.capacity2, flags, xcd_affine);
+        if (pl.k <= 15)
+            hipLaunchKernelGGL((k_scatter2<true, 512, 32, true>), dim3(grid2), dim3(512), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
+                               bucket_base, bucket_end, (const uint32_t *)nullptr, final_start, pl, out2, cursor2, (const uint32_t *)cap2_end,
+                               (uint32_t)pl.capacity2, flags, xcd_affine);
+        else
+            hipLaunchKernelGGL((k_scatter2<true, 512, 32>), dim3(grid2), dim3(512), SCATTER_LDS_NARROW, s, (const uint32_t *)out1, wg2_start,
+                               bucket_base, bucket_end, (const uint32_t *)nullptr, final_start, pl, out2, cursor2, (const uint32_t *)cap2_end,
+                               (uint32_t)pl.capacity2, flags, xcd_affine);
         final_recs = (const uint16_t *)out2; k6_start = final_start; k6_end = cursor2;   // a final bucket ends where its cursor stopped
     } else if (pl.b2) {
         hipLaunchKernelGGL(k_count2, dim3(pl.n_wg2_max), dim3(WG), 0, s, (const uint32_t *)out1, wg2_start, bucket_base, bucket_end, pl, hist2,

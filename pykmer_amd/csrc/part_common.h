@@ -105,6 +105,14 @@ __device__ __forceinline__ void hot_flush(HotTable<SLOTS> &H, unsigned long long
 }
 
 
+// Level-1 records of 32-bit k-mers (k <= 15) that go on to a second level need at most 23 bits (address bits below the
+// level-1 digit, + that digit's lowest bit rides along): they are stored as a 16-bit plane and an 8-bit plane with the
+// same record index -- 3 bytes per record instead of 4, written once and read once (0.7 GB less each way on the 800 Mbp
+// genome).  The high plane follows the low plane (and its dump tile) in the same allocation.
+__host__ __device__ __forceinline__ size_t level1_hi_plane_offset(uint64_t capacity1) {
+    return (((size_t)(capacity1 + TILE + 64) * 2u) + 255u) & ~(size_t)255u;
+}
+
 // ------------------------------------------------------------------ K2 / K5: scatter ------------
 // One tile = up to 16384 records: rank within digit by LDS atomic, exclusive scan of the digit
 // counts, records + digits parked in LDS in sorted order, then written as coalesced runs at
@@ -152,7 +160,7 @@ template <typename RIN, bool WIDE, int NT = SC_T, int PER = SC_PER, int NB = 512
 __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[PER], uint32_t okm, uint32_t n_tile,
                                              uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out,
                                              Settle &&settle, uint32_t *claim = nullptr, const uint32_t *__restrict__ cap_end = nullptr,
-                                             uint32_t dump = 0, uint32_t *overflow = nullptr) {
+                                             uint32_t dump = 0, uint32_t *overflow = nullptr, uint8_t *__restrict__ out_hi = nullptr) {
     static_assert(NT * PER == TILE, "tile shape");
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t dbits = (uint32_t)__builtin_ctz(B);
@@ -273,8 +281,10 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     // positions at a time -- the reads are unconditional then: positions past n_tile hold stale records whose digit
     // field still indexes gbase in range; only the stores are masked.  SB = 8: level 1 (32-bit k-mers) 1.47 -> 1.42 ms, level 2
     // 1.27 -> 1.24; 4 about the same, 16 loses (1.58 / 1.54), and so does any batching for 64-bit k-mers.
+    // out_hi != nullptr (and !out16): the record leaves as two planes, its low 16 bits at o[...] and bits 16-23 at out_hi[...]
     auto store_runs = [&](auto *o) {
         constexpr bool O16 = sizeof(*o) == 2;
+        const bool planes = O16 && !out16;
         if constexpr (SB == 0) {
 #pragma unroll
             for (int j = 0; j < PER; j++) {
@@ -282,7 +292,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
                 if (p < n_tile) {
                     const uint32_t r0 = L.rec[p];
                     const uint32_t d0 = WIDE ? (uint32_t)L.dig[p] : __builtin_amdgcn_ubfe(r0, shift, dbits);
-                    if (O16) o[p + L.gbase[d0]] = (uint16_t)(r0 & low_mask);
+                    if (O16) { const uint32_t at = p + L.gbase[d0]; o[at] = (uint16_t)(planes ? r0 : (r0 & low_mask)); if (planes) out_hi[at] = (uint8_t)(r0 >> 16); }
                     else o[p + L.gbase[d0]] = r0;
                 }
             }
@@ -305,7 +315,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
 #pragma unroll
                     for (int u = 0; u < SB; u++) {
                         const uint32_t p = threadIdx.x + (uint32_t)(j0 + u) * NT;
-                        if (O16) o[p + g0[u]] = (uint16_t)(r0[u] & low_mask);
+                        if (O16) { o[p + g0[u]] = (uint16_t)(planes ? r0[u] : (r0[u] & low_mask)); if (planes) out_hi[p + g0[u]] = (uint8_t)(r0[u] >> 16); }
                         else o[p + g0[u]] = r0[u];
                     }
                 } else {
@@ -313,7 +323,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
                     for (int u = 0; u < SB; u++) {
                         const uint32_t p = threadIdx.x + (uint32_t)(j0 + u) * NT;
                         if (FULL || p < n_tile) {
-                            if (O16) o[p + g0[u]] = (uint16_t)(r0[u] & low_mask);
+                            if (O16) { o[p + g0[u]] = (uint16_t)(planes ? r0[u] : (r0[u] & low_mask)); if (planes) out_hi[p + g0[u]] = (uint8_t)(r0[u] >> 16); }
                             else o[p + g0[u]] = r0[u];
                         }
                     }
@@ -321,7 +331,7 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
             }
         }
     };
-    if (out16) store_runs(reinterpret_cast<uint16_t *>(out));
+    if (out16 || out_hi) store_runs(reinterpret_cast<uint16_t *>(out));
     else store_runs(reinterpret_cast<uint32_t *>(out));
     __syncthreads();
 }

@@ -332,7 +332,7 @@ class Header(HeaderVars):
         assert table.size == self.data_size, f"{path}: {table.size} bytes, expected {self.data_size}"
         return table
 
-    def read_table_slice(self, lo: int, hi: int, index_file: str = None) -> np.ndarray:
+    def read_table_slice(self, lo: int, hi: int, index_file: str = None, threads: int = None) -> np.ndarray:
         """Table bytes [lo, hi) only: a rank of the address-range-sharded merge never touches the rest of the
         file.  Raw .kin: one positioned read.  BGZF .kin.bgz: only the blocks that cover the slice are
         inflated.  Plain gzip (what tools.py:300-302 reads through gzip.open) has no random access: the
@@ -342,7 +342,7 @@ class Header(HeaderVars):
         path = index_file or self.index_file
         if path.endswith(".bgz"):
             from . import bgzf
-            part, delivered = bgzf.decompress_range(path, lo, hi)
+            part, delivered = bgzf.decompress_range(path, lo, hi, threads=threads)   # native inflate threads for this table
         else:
             assert os.path.getsize(path) == self.data_size, f"{path}: not {self.data_size} bytes"
             # a view of the page cache, not a copy: the library moves it to HBM from several threads

@@ -118,13 +118,16 @@ def gpu_partial(headers: List[Header], lo: int, hi: int, windows, device: int, t
     assert all(resident) or not any(resident), "resident and file-backed tables cannot be mixed in one merge"
     cuts = [(lo, hi)] if all(resident) else _sub_slices(lo, hi, N, device)
     bufs = [] if all(resident) else [_lib.DeviceBuffer(max(b - a for a, b in cuts), device) for _ in range(N)]
+    from . import bgzf
+    io_threads = max(1, bgzf.INFLATE_THREADS // max(1, min(threads, N)))
     try:
         pool = ThreadPoolExecutor(max_workers=max(1, threads)) if bufs else None
         try:
             for a, b in cuts:
                 if bufs:
-                    # read / inflate on host threads (GIL released in I/O and zlib), upload as each one lands
-                    list(pool.map(lambda i: bufs[i].upload(headers[i].read_table_slice(a, b)), range(N)))
+                    # read / inflate (`threads` tables at a time, each .kin.bgz on its share of the native inflate threads),
+                    # upload as each one lands
+                    list(pool.map(lambda i: bufs[i].upload(headers[i].read_table_slice(a, b, threads=io_threads)), range(N)))
                     ptrs = [buf.ptr for buf in bufs]
                 else:
                     ptrs = [h.device_slice(a, b) for h in headers]

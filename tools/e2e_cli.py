@@ -44,8 +44,17 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("PK_TMP", "/tmp")) as d:
     out["indexer_cli_13x20Mbp_total_s"] = t_idx
     out["merger_cli_n13_k15_raw_kin_s"] = run(os.path.join(ROOT, "merger.py"), os.path.join(d, "proj"), *kins, "--threads", "8")
     t0 = time.perf_counter()
-    from pykmer_amd import bgzf
     bgzf.compress_file(kins[0], level=1, threads=16)
     out["bgzf_level1_1GiB_16thr_s"] = time.perf_counter() - t0
     t0 = time.perf_counter(); bgzf.decompress_file(kins[0] + ".bgz", threads=16); out["bgzf_inflate_1GiB_16thr_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter(); bgzf.decompress_file(kins[0] + ".bgz"); out["bgzf_inflate_1GiB_default_threads_s"] = time.perf_counter() - t0
+    out["bgzf_inflate_default_threads"] = bgzf.INFLATE_THREADS
+    # the reference's own input form: merger.py over *.kin.bgz (README.md:57-61) -- every table inflated block-parallel on
+    # native threads, only the bytes of each device slice
+    for kin in kins[1:]:
+        bgzf.compress_file(kin, level=1, threads=16)
+    bgz = [kin + ".bgz" for kin in kins]
+    out["merger_cli_n13_k15_kin_bgz_s"] = run(os.path.join(ROOT, "merger.py"), os.path.join(d, "proj_bgz"), *bgz, "--threads", "13")
+    import numpy as np
+    assert np.array_equal(np.load(os.path.join(d, "proj_bgz.001-255.kma"))["matrix"], np.load(os.path.join(d, "proj.001-255.kma"))["matrix"])
 print(json.dumps(out))
