@@ -165,6 +165,11 @@ int pk_bgzf_scan(const uint8_t *src, uint64_t n_bytes, uint64_t cap, uint64_t *c
                  uint64_t *isize_out, uint64_t *n_blocks_out);
 int pk_bgzf_inflate(const uint8_t *src, const uint64_t *c_off, const uint64_t *c_size, const uint64_t *u_off,
                     uint64_t n_blocks, uint8_t *dst, int threads);
+/* The writer (the README's `bgzip -i -I x.gzi -l 9 -c x > x.bgz` step, README.md:26): every block_input (<= 0xff00) bytes
+ * of src become one BGZF block, deflated on native threads; dst needs 65536 bytes per block, the blocks end up back to
+ * back in its first *total_out bytes (no end-of-file block), c_sizes_out[i] = size of block i (the `.gzi` follows). */
+int pk_bgzf_deflate(const uint8_t *src, uint64_t n_bytes, int level, uint32_t block_input, uint8_t *dst, uint64_t dst_cap,
+                    uint64_t *c_sizes_out, uint64_t *total_out, int threads);
 
 /* ---- diagnostics (tools/, tests/): no reference counterpart, no effect on any result.
  * pk_diag_occupancy: workgroups per CU the runtime grants kernel `which` (0 k_bucket_count_half, 1 k_bucket_count_bytes,

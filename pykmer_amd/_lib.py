@@ -54,6 +54,8 @@ _SIGNATURES = {
     "pk_gram_expand": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "pk_bgzf_scan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _u64p]),
     "pk_bgzf_inflate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int]),
+    "pk_bgzf_deflate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
+                                        ctypes.c_void_p, _u64p, ctypes.c_int]),
     "pk_diag_occupancy": (ctypes.c_int, [ctypes.c_int]),
     "pk_diag_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p]),
 }
@@ -321,6 +323,17 @@ def bgzf_inflate(buf: np.ndarray, c_off, c_size, u_off, out: np.ndarray, threads
     uo = np.ascontiguousarray(np.asarray(u_off, dtype=np.int64) - int(u_off[0]), dtype=np.uint64)
     assert uo.size == n + 1 and out.dtype == np.uint8 and out.flags.c_contiguous and out.size >= int(uo[-1])
     _check(load().pk_bgzf_inflate(buf.ctypes.data, co.ctypes.data, cs.ctypes.data, uo.ctypes.data, n, out.ctypes.data, int(threads)))
+
+
+def bgzf_deflate(data: np.ndarray, level: int, block_input: int, threads: int):
+    """pk_bgzf_deflate: (compressed blocks back to back as a u8 array, per-block compressed sizes)."""
+    n_blocks = (data.size + block_input - 1) // block_input
+    dst = np.empty(max(1, n_blocks) * 65536, dtype=np.uint8)
+    sizes = np.zeros(max(1, n_blocks), dtype=np.uint64)
+    total = ctypes.c_uint64(0)
+    _check(load().pk_bgzf_deflate(data.ctypes.data, data.size, level, block_input, dst.ctypes.data, dst.size, sizes.ctypes.data,
+                                  ctypes.byref(total), int(threads)))
+    return dst[: total.value], sizes[:n_blocks].astype(np.int64)
 
 
 def diag_plan(k: int, n_bytes: int = 0) -> dict:

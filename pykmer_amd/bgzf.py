@@ -6,7 +6,7 @@ README.md:26, data/README.md:24) and reads them back through one single-threaded
 their compressed size in a `BC` extra field (SAM spec 4.1), so both directions parallelise over
 blocks.  Reading goes through the library (pk_bgzf_scan / pk_bgzf_inflate, csrc/bgzf_host.cpp: zlib on native threads
 straight into the destination array -- from Python threads the per-block interpreter work capped a 1 GiB table at ~1 GB/s);
-the writer deflates on Python threads (zlib releases the GIL).  The `.gzi` index is the layout
+the writer goes the same way (pk_bgzf_deflate).  The `.gzi` index is the layout
 gzireader.py:12-34 prints: u64 count, then (compressed_offset, uncompressed_offset) u64 pairs for
 every block but the first.
 
@@ -17,7 +17,6 @@ import gzip
 import os
 import struct
 import zlib
-from concurrent.futures import ThreadPoolExecutor
 from typing import List, Tuple
 
 import numpy as np
@@ -25,40 +24,32 @@ import numpy as np
 BLOCK_INPUT = 0xFF00                    # uncompressed bytes per block (htslib BGZF_BLOCK_SIZE)
 _HEADER = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00"
 EOF_BLOCK = _HEADER + struct.pack("<H", 27) + b"\x03\x00" + struct.pack("<II", 0, 0)
-DEFAULT_THREADS = max(1, min(16, os.cpu_count() or 1))          # deflate (Python threads)
-INFLATE_THREADS = max(1, min(64, len(os.sched_getaffinity(0))))  # inflate (native threads)
+INFLATE_THREADS = max(1, min(64, len(os.sched_getaffinity(0))))  # native threads of the library calls (inflate and deflate)
+DEFAULT_THREADS = INFLATE_THREADS
 
 
-def _deflate_block(data: bytes, level: int) -> bytes:
-    co = zlib.compressobj(level, zlib.DEFLATED, -15)
-    body = co.compress(data) + co.flush()
-    if len(body) + 26 > 0x10000:        # incompressible input: store it (level 0 always fits 0xFF00 bytes)
-        co = zlib.compressobj(0, zlib.DEFLATED, -15)
-        body = co.compress(data) + co.flush()
-    return _HEADER + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", zlib.crc32(data), len(data))
-
-
-def compress_file(src: str, dst: str = None, level: int = 9, threads: int = DEFAULT_THREADS, index: bool = True,
-                  batch_blocks: int = 512) -> Tuple[str, str]:
+def compress_file(src: str, dst: str = None, level: int = 9, threads: int = None, index: bool = True,
+                  batch_blocks: int = 4096) -> Tuple[str, str]:
     """`bgzip -i -I dst.gzi -l 9 -c src > dst`: writes dst (default src + '.bgz') via .tmp + rename and,
-    if `index`, dst + '.gzi'.  Returns (dst, gzi path or None)."""
+    if `index`, dst + '.gzi'.  Returns (dst, gzi path or None).  The blocks are deflated by the library on native
+    threads (pk_bgzf_deflate), `batch_blocks` at a time."""
     dst = dst or src + ".bgz"
     tmp = dst + ".tmp"
     entries: List[Tuple[int, int]] = []
     c_off = u_off = 0
-    with open(src, "rb") as fin, open(tmp, "wb") as fout, ThreadPoolExecutor(max_workers=threads) as pool:
-        while True:
-            chunk = fin.read(BLOCK_INPUT * batch_blocks)
-            if not chunk:
-                break
-            view = memoryview(chunk)
-            pieces = [view[i:i + BLOCK_INPUT] for i in range(0, len(chunk), BLOCK_INPUT)]
-            for piece, blk in zip(pieces, pool.map(lambda p: _deflate_block(bytes(p), level), pieces)):
+    size = os.path.getsize(src)
+    raw = np.memmap(src, dtype=np.uint8, mode="r") if size else np.zeros(0, np.uint8)
+    step = BLOCK_INPUT * batch_blocks
+    with open(tmp, "wb") as fout:
+        for at in range(0, size, step):
+            chunk = np.ascontiguousarray(raw[at:at + step])
+            packed, sizes = _native().bgzf_deflate(chunk, level, BLOCK_INPUT, threads or INFLATE_THREADS)
+            for i, z in enumerate(sizes):
                 if c_off:                                    # htslib lists every block except the first
                     entries.append((c_off, u_off))
-                fout.write(blk)
-                c_off += len(blk)
-                u_off += len(piece)
+                c_off += int(z)
+                u_off += min(BLOCK_INPUT, chunk.size - i * BLOCK_INPUT)
+            fout.write(packed.data)
         fout.write(EOF_BLOCK)
     os.replace(tmp, dst)
     gzi = None

@@ -8,6 +8,7 @@
 // zlib on std::threads straight into the caller's buffer, CRC32 and ISIZE checked per block (SAM spec 4.1).
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstring>
@@ -98,5 +99,74 @@ extern "C" int pk_bgzf_inflate(const uint8_t *src, const uint64_t *c_off, const 
     work();
     for (auto &t : th) t.join();
     if (failed.load()) return pk::set_error(PK_ERR_ARG, why[0]);
+    return PK_OK;
+}
+
+// The writer's side (README.md:26: `bgzip -i -I x.gzi -l 9 -c x > x.bgz`): every `block_input` bytes of `src` become one
+// BGZF block (gzip member with the BC field, raw deflate at `level`, CRC32 + ISIZE), deflated on native threads.  Block i
+// is first written at dst + i * 65536 (a block never exceeds 64 KiB: input that does not compress is stored), then the
+// blocks are moved together; the end-of-file block is NOT appended (the caller writes it).  dst needs n_blocks * 65536
+// bytes.  c_sizes_out[i] = size of block i; *total_out = bytes of dst in use.
+extern "C" int pk_bgzf_deflate(const uint8_t *src, uint64_t n_bytes, int level, uint32_t block_input, uint8_t *dst, uint64_t dst_cap,
+                               uint64_t *c_sizes_out, uint64_t *total_out, int threads) {
+    if (!total_out || (n_bytes && (!src || !dst || !c_sizes_out))) return pk::set_error(PK_ERR_ARG, "null argument");
+    if (block_input == 0 || block_input > 0xff00u) return pk::set_error(PK_ERR_ARG, "a BGZF block holds at most 0xff00 input bytes");
+    if (level < 0 || level > 9) return pk::set_error(PK_ERR_ARG, "deflate level 0..9");
+    const uint64_t n_blocks = (n_bytes + block_input - 1) / block_input;
+    *total_out = 0;
+    if (n_blocks == 0) return PK_OK;
+    if (dst_cap < n_blocks * 65536ull) return pk::set_error(PK_ERR_ARG, "destination too small: 65536 bytes per block");
+    if (threads < 1) threads = 1;
+    if ((uint64_t)threads > n_blocks) threads = (int)n_blocks;
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> failed{0};
+    auto work = [&]() {
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        // what Python's zlib.compressobj(level, DEFLATED, -15) sets up: the bytes are those the Python writer produced
+        if (deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { failed.store(1); return; }
+        for (;;) {
+            const uint64_t b = next.fetch_add(1);
+            if (b >= n_blocks || failed.load()) break;
+            const uint8_t *in = src + b * block_input;
+            const uint32_t len = (uint32_t)std::min<uint64_t>(block_input, n_bytes - b * block_input);
+            uint8_t *out = dst + b * 65536ull;
+            static const uint8_t head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 'B', 'C', 0x02, 0x00};
+            memcpy(out, head, 16);
+            uint32_t body = 0;
+            for (int attempt = 0; attempt < 2; attempt++) {
+                if (attempt == 1) deflateParams(&z, 0, Z_DEFAULT_STRATEGY);       // did not fit: store it (level 0 always fits 0xff00 bytes)
+                deflateReset(&z);
+                z.next_in = const_cast<Bytef *>(in); z.avail_in = len;
+                z.next_out = out + 18; z.avail_out = 65536 - 18 - 8;
+                const int rc = deflate(&z, Z_FINISH);
+                if (rc == Z_STREAM_END) { body = (uint32_t)(65536 - 18 - 8 - z.avail_out); break; }
+                if (attempt == 1) failed.store(1);
+            }
+            if (z.total_in && level && body == 0) { failed.store(1); break; }
+            if (failed.load()) break;
+            if (body + 26 > 0x10000u) { failed.store(1); break; }
+            // restore the level for the next block if this one had to be stored
+            deflateParams(&z, level, Z_DEFAULT_STRATEGY);
+            const uint32_t bsize = body + 25;                                    // total block size - 1
+            out[16] = (uint8_t)bsize; out[17] = (uint8_t)(bsize >> 8);
+            const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in, len);
+            uint8_t *tail = out + 18 + body;
+            for (int i = 0; i < 4; i++) { tail[i] = (uint8_t)(crc >> (8 * i)); tail[4 + i] = (uint8_t)(len >> (8 * i)); }
+            c_sizes_out[b] = body + 26;
+        }
+        deflateEnd(&z);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (failed.load()) return pk::set_error(PK_ERR_ARG, "deflate failed");
+    uint64_t at = 0;
+    for (uint64_t b = 0; b < n_blocks; b++) {                                    // move the blocks together
+        if (at != b * 65536ull) memmove(dst + at, dst + b * 65536ull, c_sizes_out[b]);
+        at += c_sizes_out[b];
+    }
+    *total_out = at;
     return PK_OK;
 }
