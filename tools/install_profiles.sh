@@ -19,3 +19,5 @@ if [ -f $O/pmc_fetch_k17/fetch_counter_collection.csv ]; then
   cp $O/stats_k17/ks_kernel_stats.csv $P/${R}_k17_kernel_stats.csv
   python tools/hbm_traffic.py $P/${R}_k17_pmc_fetch_counter_collection.csv $P/${R}_k17_pmc_write_counter_collection.csv > $P/hbm_traffic_k17.json
 fi
+for f in gram_sweeps.txt pmc_sq_k17.txt step_trace_gaps.txt; do [ -f $O/$f ] && cp $O/$f $P/${R}_$f; done
+true

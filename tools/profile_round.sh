@@ -24,3 +24,8 @@ PK_TMP=/dev/shm timeout -k 10 400 python tools/e2e_cli.py > $O/e2e_cli.json
 timeout -k 10 300 python tools/profile_mix.py > $O/profile_mix.txt 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq -o sq -- python3 bench.py --steps 2 --warmup 0 --no-cpu --no-merge --no-e2e > $O/pmc_sq.log
 find $O -name "*.csv" | head -20
+# round 3 additions: threshold sweeps (k_gram_mw) against one scan, SQ counters of the k=17 step, a step's dispatch trace
+timeout -k 10 300 python tools/bench_gram.py 13 32 > $O/gram_sweeps.txt 2>&1
+bash tools/pmc_sq.sh 17 > /dev/null 2>&1 && cp gpurun_out/pmc_sq_17.txt $O/pmc_sq_k17.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-merge --no-e2e > $O/bench_traced.json 2>/dev/null
+python tools/trace_gaps.py $O/trace > $O/step_trace_gaps.txt 2>&1
