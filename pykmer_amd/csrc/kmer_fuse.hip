@@ -364,7 +364,7 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
         }
         // 32-bit k-mers with a second level to come: 3-byte records in two planes (part_common.h)
         uint8_t *out_hi = (!WIDE && !out16) ? reinterpret_cast<uint8_t *>(out) + level1_hi_plane_offset(pl.capacity1) : nullptr;
-        scatter_tile<KT, WIDE, NT, PER, NB, false, PK_PB_L1, (WIDE ? 0 : PK_SB_L1)>(L, r, okm, ~0u, shift, B, low_mask, out16, out, settle, cursor1, cap_end, dump, flags, out_hi);
+        scatter_tile<KT, WIDE, NT, PER, NB, false, PK_PB_L1, (WIDE ? 0 : PK_SB_L1), !WIDE>(L, r, okm, ~0u, shift, B, low_mask, out16, out, settle, cursor1, cap_end, dump, flags, out_hi);
         if (hot.used >= HS / 2) hot_flush(hot, side, side_n, side_cap);   // uniform: read after the barrier that ends the tile
     }
     if (COUNT) {

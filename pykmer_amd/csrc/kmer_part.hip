@@ -295,8 +295,8 @@ __global__ __launch_bounds__(NT, 4) void k_scatter2(const uint32_t *__restrict__
             if (win + TILE < hi) fetch(win + TILE, nxt);
             uint32_t *cl = CLAIM ? cursor + (uint64_t)b * B : nullptr;
             const uint32_t *ce = CLAIM ? cap_end + (uint64_t)b * B : nullptr;
-            if (full) scatter_tile<uint32_t, false, NT, PER, 512, true, PK_PB_L2, PK_SB_L2>(L, r, 0u, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
-            else scatter_tile<uint32_t, false, NT, PER, 512, false, PK_PB_L2, PK_SB_L2>(L, r, okm, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
+            if (full) scatter_tile<uint32_t, false, NT, PER, 512, true, PK_PB_L2, PK_SB_L2, REC24>(L, r, 0u, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
+            else scatter_tile<uint32_t, false, NT, PER, 512, false, PK_PB_L2, PK_SB_L2, REC24>(L, r, okm, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
         }
     };
     if (!CLAIM) {

@@ -156,7 +156,10 @@ constexpr size_t SCATTER_LDS_WIDE = sizeof(ScatterLds);            // 104 KiB
 // (off[d] ends at the start of run d + 1; gbase keeps the starts).  Round 1 ranked with one returning add and kept
 // digit and rank of every record in a register until the scan was done: 16 or 32 more live registers and three to
 // four more vector instructions per record, in kernels that are bound by instruction issue.
-template <typename RIN, bool WIDE, int NT = SC_T, int PER = SC_PER, int NB = 512, bool FULL = false, int PB = 0, int SB = 0, class Settle>
+// OFF32: every output index of this kernel is below 2^31 (the host cuts feeds of 32-bit k-mers so that both bucket areas
+// stay below that: feed_piece), so byte offsets fit 32 bits and the stores take a scalar base + a 32-bit lane offset
+// instead of a 64-bit address per record.
+template <typename RIN, bool WIDE, int NT = SC_T, int PER = SC_PER, int NB = 512, bool FULL = false, int PB = 0, int SB = 0, bool OFF32 = false, class Settle>
 __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[PER], uint32_t okm, uint32_t n_tile,
                                              uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out,
                                              Settle &&settle, uint32_t *claim = nullptr, const uint32_t *__restrict__ cap_end = nullptr,
@@ -285,6 +288,13 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     auto store_runs = [&](auto *o) {
         constexpr bool O16 = sizeof(*o) == 2;
         const bool planes = O16 && !out16;
+        // OFF32: the byte offset is formed in 32 bits, so the store takes the scalar base + a 32-bit lane offset (the
+        // compiler does not derive that from an assumption on the index: it needs to see the 32-bit arithmetic)
+        auto put = [&](uint32_t at, uint32_t v) {
+            if (OFF32) *reinterpret_cast<decltype(o)>(reinterpret_cast<uint8_t *>(o) + (uint32_t)(at * (uint32_t)sizeof(*o))) = (decltype(*o + 0))v;
+            else o[at] = v;
+        };
+        auto idx32 = [](uint32_t at) -> uint32_t { return at; };
         if constexpr (SB == 0) {
 #pragma unroll
             for (int j = 0; j < PER; j++) {
@@ -292,8 +302,9 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
                 if (p < n_tile) {
                     const uint32_t r0 = L.rec[p];
                     const uint32_t d0 = WIDE ? (uint32_t)L.dig[p] : __builtin_amdgcn_ubfe(r0, shift, dbits);
-                    if (O16) { const uint32_t at = p + L.gbase[d0]; o[at] = (uint16_t)(planes ? r0 : (r0 & low_mask)); if (planes) out_hi[at] = (uint8_t)(r0 >> 16); }
-                    else o[p + L.gbase[d0]] = r0;
+                    const uint32_t at = idx32(p + L.gbase[d0]);
+                    if (O16) { put(at, (uint16_t)(planes ? r0 : (r0 & low_mask))); if (planes) out_hi[at] = (uint8_t)(r0 >> 16); }
+                    else put(at, r0);
                 }
             }
         } else {
@@ -315,16 +326,18 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
 #pragma unroll
                     for (int u = 0; u < SB; u++) {
                         const uint32_t p = threadIdx.x + (uint32_t)(j0 + u) * NT;
-                        if (O16) { o[p + g0[u]] = (uint16_t)(planes ? r0[u] : (r0[u] & low_mask)); if (planes) out_hi[p + g0[u]] = (uint8_t)(r0[u] >> 16); }
-                        else o[p + g0[u]] = r0[u];
+                        const uint32_t at = idx32(p + g0[u]);
+                        if (O16) { put(at, (uint16_t)(planes ? r0[u] : (r0[u] & low_mask))); if (planes) out_hi[at] = (uint8_t)(r0[u] >> 16); }
+                        else put(at, r0[u]);
                     }
                 } else {
 #pragma unroll
                     for (int u = 0; u < SB; u++) {
                         const uint32_t p = threadIdx.x + (uint32_t)(j0 + u) * NT;
                         if (FULL || p < n_tile) {
-                            if (O16) { o[p + g0[u]] = (uint16_t)(planes ? r0[u] : (r0[u] & low_mask)); if (planes) out_hi[p + g0[u]] = (uint8_t)(r0[u] >> 16); }
-                            else o[p + g0[u]] = r0[u];
+                            const uint32_t at = idx32(p + g0[u]);
+                            if (O16) { put(at, (uint16_t)(planes ? r0[u] : (r0[u] & low_mask))); if (planes) out_hi[at] = (uint8_t)(r0[u] >> 16); }
+                            else put(at, r0[u]);
                         }
                     }
                 }

@@ -367,10 +367,13 @@ static int ensure_recs(pk_indexer *ix, uint64_t need) {
 // sort -> level 2 -> bucket count.  Record positions are 32-bit: both bucket areas (their capacity + the dump tile) must
 // end below 2^32 records.  The worst plan is k = 17 (2^18 final buckets x 4104 records of fixed slack + 25 % on the
 // estimate): 2 GiB of text -> capacity2 = 3.76e9.  feed_piece checks the plan it actually got and refuses otherwise.
+// 32-bit k-mers (k <= 15): 1 GiB pieces, record positions below 2^31 -- their sort kernels store through 32-bit byte
+// offsets (part_common.h: OFF32).
 static const uint64_t FEED_MAX = 2ULL << 30;
+static uint64_t feed_max_for(int k) { return k <= 15 ? (1ULL << 30) : FEED_MAX; }
 
 static bool plan_fits_u32(const PartPlan &pl) {
-    const uint64_t lim = (1ULL << 32) - (16384 + 64);          // the dump tile behind the buckets (part_common.h: TILE)
+    const uint64_t lim = (pl.k <= 15 ? (1ULL << 31) : (1ULL << 32)) - (16384 + 64);   // the dump tile behind the buckets (part_common.h: TILE)
     return pl.capacity1 < lim && pl.capacity2 < lim;
 }
 
@@ -379,9 +382,9 @@ extern "C" int pk_diag_plan(int k, uint64_t n_bytes, uint64_t out[8]) {
     if (!out) return fail(PK_ERR_ARG, "null output");
     int rc = check_k(k, k > 17 ? 2 * k - 34 : 0, 0);
     if (rc) return rc;
-    if (n_bytes == 0) n_bytes = FEED_MAX;
+    if (n_bytes == 0) n_bytes = feed_max_for(k);
     const PartPlan pl = make_part_plan((uint32_t)k, n_bytes, k > 17 ? (uint32_t)(2 * k - 34) : 0u, 0u);
-    out[0] = FEED_MAX; out[1] = pl.capacity1; out[2] = pl.capacity2; out[3] = pl.B1; out[4] = pl.B2; out[5] = pl.fb_bits;
+    out[0] = feed_max_for(k); out[1] = pl.capacity1; out[2] = pl.capacity2; out[3] = pl.B1; out[4] = pl.B2; out[5] = pl.fb_bits;
     out[6] = pl.n_chunks; out[7] = plan_fits_u32(pl) ? 1 : 0;
     return PK_OK;
 }
@@ -478,8 +481,9 @@ extern "C" int pk_indexer_feed_device(pk_indexer *ix, const void *dev_fasta, uin
     if (n_bytes > (1ULL << 40)) return fail(PK_ERR_ARG, "feed of %llu bytes too large; split it", (unsigned long long)n_bytes);
     HIPCHK(hipSetDevice(ix->device));
     const uint8_t *f = (const uint8_t *)dev_fasta;
-    for (uint64_t off = 0; off < n_bytes; off += FEED_MAX) {       // FEED_MAX is a multiple of 16: pieces stay aligned
-        int rc = feed_piece(ix, f + off, std::min(FEED_MAX, n_bytes - off));
+    const uint64_t piece_max = feed_max_for(ix->k);                 // a multiple of 16: pieces stay aligned
+    for (uint64_t off = 0; off < n_bytes; off += piece_max) {
+        int rc = feed_piece(ix, f + off, std::min(piece_max, n_bytes - off));
         if (rc) return rc;
     }
     return PK_OK;

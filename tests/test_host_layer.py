@@ -47,12 +47,13 @@ def test_feed_pieces_keep_record_positions_in_32_bits():
     """Record positions inside one feed piece are 32-bit (bucket starts, cursors, limits): the largest piece the library
     cuts a feed into must leave both bucket areas + the dump tile below 2^32 for every k -- k = 17 with its 2^18 final
     buckets of fixed slack is the tight one -- and a plan that does not fit is refused, not wrapped."""
-    feed_max = _lib.diag_plan(15)["feed_max"]
-    assert feed_max % 16 == 0
     for k in (3, 9, 13, 15, 17, 19, 21):
         pl = _lib.diag_plan(k)                          # n_bytes = 0: the largest piece
+        assert pl["feed_max"] % 16 == 0
         assert pl["fits_u32"] == 1, (k, pl)
-        assert max(pl["capacity1"], pl["capacity2"]) + 16384 + 64 < 2 ** 32, (k, pl)
+        # 32-bit k-mers store through 32-bit BYTE offsets (2-byte records): their positions stay below 2^31
+        assert max(pl["capacity1"], pl["capacity2"]) + 16384 + 64 < (2 ** 31 if k <= 15 else 2 ** 32), (k, pl)
+    assert _lib.diag_plan(15, 2 << 30)["fits_u32"] == 0
     assert _lib.diag_plan(17, 3 << 30)["fits_u32"] == 0                            # the old 3 GiB piece did not fit at k = 17
 
 
