@@ -160,11 +160,12 @@ int pk_gram_expand(const uint64_t *pair, int N, uint64_t *matrix_out);
  * pk_bgzf_scan: walks the member headers of `src` (no inflation): offset, size and ISIZE of each; PK_ERR_ARG if the
  * bytes are not BGZF; PK_ERR_RECS_CAP if more than `cap` blocks (*n_blocks_out = the count; call again with room).
  * pk_bgzf_inflate: block i (c_off[i], c_size[i]) -> dst + u_off[i], u_off[i + 1] - u_off[i] bytes (u_off has n_blocks + 1
- * entries); CRC32 and ISIZE of every block are checked (SAM spec 4.1). */
+ * entries); the block list is checked against src_bytes (it may come from a `.gzi` file), CRC32 and ISIZE of every
+ * block against its payload (SAM spec 4.1). */
 int pk_bgzf_scan(const uint8_t *src, uint64_t n_bytes, uint64_t cap, uint64_t *c_off_out, uint64_t *c_size_out,
                  uint64_t *isize_out, uint64_t *n_blocks_out);
-int pk_bgzf_inflate(const uint8_t *src, const uint64_t *c_off, const uint64_t *c_size, const uint64_t *u_off,
-                    uint64_t n_blocks, uint8_t *dst, int threads);
+int pk_bgzf_inflate(const uint8_t *src, uint64_t src_bytes, const uint64_t *c_off, const uint64_t *c_size,
+                    const uint64_t *u_off, uint64_t n_blocks, uint8_t *dst, int threads);
 /* The writer (the README's `bgzip -i -I x.gzi -l 9 -c x > x.bgz` step, README.md:26): every block_input (<= 0xff00) bytes
  * of src become one BGZF block, deflated on native threads; dst needs 65536 bytes per block, the blocks end up back to
  * back in its first *total_out bytes (no end-of-file block), c_sizes_out[i] = size of block i (the `.gzi` follows). */

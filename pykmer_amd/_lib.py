@@ -53,7 +53,8 @@ _SIGNATURES = {
                                                           ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "pk_gram_expand": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "pk_bgzf_scan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _u64p]),
-    "pk_bgzf_inflate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int]),
+    "pk_bgzf_inflate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                        ctypes.c_int]),
     "pk_bgzf_deflate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
                                         ctypes.c_void_p, _u64p, ctypes.c_int]),
     "pk_diag_occupancy": (ctypes.c_int, [ctypes.c_int]),
@@ -322,7 +323,7 @@ def bgzf_inflate(buf: np.ndarray, c_off, c_size, u_off, out: np.ndarray, threads
     cs = np.ascontiguousarray(c_size, dtype=np.uint64)
     uo = np.ascontiguousarray(np.asarray(u_off, dtype=np.int64) - int(u_off[0]), dtype=np.uint64)
     assert uo.size == n + 1 and out.dtype == np.uint8 and out.flags.c_contiguous and out.size >= int(uo[-1])
-    _check(load().pk_bgzf_inflate(buf.ctypes.data, co.ctypes.data, cs.ctypes.data, uo.ctypes.data, n, out.ctypes.data, int(threads)))
+    _check(load().pk_bgzf_inflate(buf.ctypes.data, buf.size, co.ctypes.data, cs.ctypes.data, uo.ctypes.data, n, out.ctypes.data, int(threads)))
 
 
 def bgzf_deflate(data: np.ndarray, level: int, block_input: int, threads: int):

@@ -52,10 +52,14 @@ extern "C" int pk_bgzf_scan(const uint8_t *src, uint64_t n_bytes, uint64_t cap, 
     return nb > cap ? pk::set_error(PK_ERR_RECS_CAP, "more BGZF blocks than the caller's arrays hold") : PK_OK;
 }
 
-extern "C" int pk_bgzf_inflate(const uint8_t *src, const uint64_t *c_off, const uint64_t *c_size, const uint64_t *u_off, uint64_t n_blocks,
-                               uint8_t *dst, int threads) {
+extern "C" int pk_bgzf_inflate(const uint8_t *src, uint64_t src_bytes, const uint64_t *c_off, const uint64_t *c_size, const uint64_t *u_off,
+                               uint64_t n_blocks, uint8_t *dst, int threads) {
     if (n_blocks == 0) return PK_OK;
     if (!src || !c_off || !c_size || !u_off || !dst) return pk::set_error(PK_ERR_ARG, "null argument");
+    for (uint64_t b = 0; b < n_blocks; b++)                   // the index may come from a `.gzi` file: trust nothing
+        if (c_size[b] < 26 || c_off[b] > src_bytes || c_size[b] > src_bytes - c_off[b] || u_off[b + 1] < u_off[b] ||
+            (uint64_t)rd16(src + c_off[b] + 10) + 20 > c_size[b])
+            return pk::set_error(PK_ERR_ARG, "BGZF block " + std::to_string(b) + ": the block index does not fit the file");
     if (threads < 1) threads = 1;
     if ((uint64_t)threads > n_blocks) threads = (int)n_blocks;
     std::atomic<uint64_t> next{0};
@@ -121,10 +125,12 @@ extern "C" int pk_bgzf_deflate(const uint8_t *src, uint64_t n_bytes, int level, 
     std::atomic<uint64_t> next{0};
     std::atomic<int> failed{0};
     auto work = [&]() {
-        z_stream z;
-        memset(&z, 0, sizeof z);
-        // what Python's zlib.compressobj(level, DEFLATED, -15) sets up: the bytes are those the Python writer produced
+        // two streams per thread: `level`, set up like Python's zlib.compressobj(level, DEFLATED, -15) (the bytes are those
+        // the Python writer produced), and level 0 for a block that does not compress into 64 KiB (stored: always fits)
+        z_stream z, z0;
+        memset(&z, 0, sizeof z); memset(&z0, 0, sizeof z0);
         if (deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { failed.store(1); return; }
+        if (deflateInit2(&z0, 0, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { deflateEnd(&z); failed.store(1); return; }
         for (;;) {
             const uint64_t b = next.fetch_add(1);
             if (b >= n_blocks || failed.load()) break;
@@ -134,20 +140,14 @@ extern "C" int pk_bgzf_deflate(const uint8_t *src, uint64_t n_bytes, int level, 
             static const uint8_t head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 'B', 'C', 0x02, 0x00};
             memcpy(out, head, 16);
             uint32_t body = 0;
-            for (int attempt = 0; attempt < 2; attempt++) {
-                if (attempt == 1) deflateParams(&z, 0, Z_DEFAULT_STRATEGY);       // did not fit: store it (level 0 always fits 0xff00 bytes)
-                deflateReset(&z);
-                z.next_in = const_cast<Bytef *>(in); z.avail_in = len;
-                z.next_out = out + 18; z.avail_out = 65536 - 18 - 8;
-                const int rc = deflate(&z, Z_FINISH);
-                if (rc == Z_STREAM_END) { body = (uint32_t)(65536 - 18 - 8 - z.avail_out); break; }
-                if (attempt == 1) failed.store(1);
+            bool done = false;
+            for (z_stream *zs : {&z, &z0}) {
+                deflateReset(zs);
+                zs->next_in = const_cast<Bytef *>(in); zs->avail_in = len;
+                zs->next_out = out + 18; zs->avail_out = 65536 - 18 - 8;
+                if (deflate(zs, Z_FINISH) == Z_STREAM_END) { body = (uint32_t)(65536 - 18 - 8 - zs->avail_out); done = true; break; }
             }
-            if (z.total_in && level && body == 0) { failed.store(1); break; }
-            if (failed.load()) break;
-            if (body + 26 > 0x10000u) { failed.store(1); break; }
-            // restore the level for the next block if this one had to be stored
-            deflateParams(&z, level, Z_DEFAULT_STRATEGY);
+            if (!done || body + 26 > 0x10000u) { failed.store(1); break; }
             const uint32_t bsize = body + 25;                                    // total block size - 1
             out[16] = (uint8_t)bsize; out[17] = (uint8_t)(bsize >> 8);
             const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in, len);
@@ -155,7 +155,7 @@ extern "C" int pk_bgzf_deflate(const uint8_t *src, uint64_t n_bytes, int level, 
             for (int i = 0; i < 4; i++) { tail[i] = (uint8_t)(crc >> (8 * i)); tail[4 + i] = (uint8_t)(len >> (8 * i)); }
             c_sizes_out[b] = body + 26;
         }
-        deflateEnd(&z);
+        deflateEnd(&z); deflateEnd(&z0);
     };
     std::vector<std::thread> th;
     for (int t = 1; t < threads; t++) th.emplace_back(work);

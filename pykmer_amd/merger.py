@@ -278,7 +278,7 @@ def parse_sweep(text: str):
     return out
 
 
-def spawn_ranks(world: int, argv: List[str]) -> int:
+def spawn_ranks(world: int, argv: List[str], script: str = None) -> int:
     """`merger.py ... --gpus N` without a launcher: start N ranks of this command line (one per GPU) and wait for them.
     The parent never touches a GPU (the root CLI skips its warm-up thread in this case), so the ranks are plain child
     processes of a process without a HIP context.  Rank 0 inherits stdout; the others print nothing."""
@@ -289,7 +289,9 @@ def spawn_ranks(world: int, argv: List[str]) -> int:
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, os.path.abspath(sys.argv[0])] + list(argv)
+    # the root CLI, whoever called main(): a rank must not start whatever sys.argv[0] happens to be (a test runner, say)
+    script = script or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "merger.py")
+    cmd = [sys.executable, script] + list(argv)
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

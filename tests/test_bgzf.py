@@ -178,3 +178,37 @@ def test_block_index_and_pieces(tmp_path, monkeypatch):
     empty.write_bytes(b"")
     dst0, _ = bgzf.compress_file(str(empty))
     assert list(bgzf.iter_pieces(dst0, 100)) == []
+
+
+def test_native_reader_rejects_a_lying_index_and_corrupt_blocks(tmp_path):
+    """pk_bgzf_inflate is handed block lists that may come from a `.gzi` file: offsets past the file, sizes that do not match,
+    a flipped payload bit (CRC) -- all must come back as errors, never as reads outside the buffers."""
+    from pykmer_amd import _lib
+    src = tmp_path / "t.bin"
+    data = _table(300_000, 5)
+    data.tofile(src)
+    dst, _ = bgzf.compress_file(str(src))
+    raw = np.fromfile(dst, dtype=np.uint8)
+    c_offs, c_sizes, u_offs = bgzf.block_index(dst)
+    out = np.empty(data.size, dtype=np.uint8)
+    _lib.bgzf_inflate(raw, c_offs, c_sizes, u_offs, out, 3)
+    assert np.array_equal(out, data)
+    bad = c_offs.copy(); bad[-1] = raw.size - 5
+    with pytest.raises(ValueError):
+        _lib.bgzf_inflate(raw, bad, c_sizes, u_offs, out, 3)
+    bad = c_sizes.copy(); bad[0] = 10
+    with pytest.raises(ValueError):
+        _lib.bgzf_inflate(raw, c_offs, bad, u_offs, out, 3)
+    bad = u_offs.copy(); bad[1] -= 1                                     # ISIZE no longer matches the room
+    with pytest.raises(ValueError):
+        _lib.bgzf_inflate(raw, c_offs, c_sizes, bad, np.empty(data.size, np.uint8), 3)
+    flipped = raw.copy(); flipped[int(c_offs[1]) + 40] ^= 0x10
+    with pytest.raises(ValueError):
+        _lib.bgzf_inflate(flipped, c_offs, c_sizes, u_offs, out, 3)
+    # mixed content: an incompressible block between compressible ones is stored, the level is back for the next one
+    mix = np.concatenate([data[:100_000], np.random.default_rng(2).integers(0, 256, 65280, dtype=np.uint8), data[:100_000]])
+    (tmp_path / "m.bin").write_bytes(mix.tobytes())
+    m_dst, _ = bgzf.compress_file(str(tmp_path / "m.bin"))
+    assert gzip.decompress(open(m_dst, "rb").read()) == mix.tobytes()
+    sizes = bgzf.block_index(m_dst)[1]
+    assert sizes.max() <= 0x10000 and sizes[0] < 30_000 and sizes[-1] < 30_000

@@ -108,6 +108,37 @@ def test_full_config4_k17(gpu):
               f"{int(hist[1:].sum())} distinct k-mers")
 
 
+def test_device_feed_larger_than_one_piece(gpu):
+    """pk_indexer_feed_device cuts a buffer into pieces (1 GiB for 32-bit k-mers: record positions stay below 2^31 there) at
+    arbitrary bytes -- mid-line, mid-k-mer.  1.6 GB in HBM (the C2 genome twice, as two records sets in one stream) in ONE call
+    must give what the same bytes give fed host-side in 256 MiB pieces, which in turn is checked against the reference's
+    golden by test_full_config2_k15 (a table with every count doubled, saturating)."""
+    import torch
+    data = np.frombuffer(inputs.make_input({"gen": "c2"}), dtype=np.uint8)
+    both = np.concatenate([data, data])
+    assert both.size > (1 << 30) + (1 << 29)
+    d = torch.empty(both.size + 64, dtype=torch.uint8, device="cuda")
+    d[: both.size].copy_(torch.from_numpy(both))
+    torch.cuda.synchronize()
+    with gpu.Indexer(15) as ix:
+        ix.feed_device(d.data_ptr(), int(both.size))
+        one = ix.finish()
+        assert ix.timings()["feeds"] == 2                                # cut once, at 1 GiB
+        t_one = ix.table_to_host()
+    del d
+    torch.cuda.empty_cache()
+    with gpu.Indexer(15) as ix:
+        ix.feed(both)
+        two = ix.finish()
+        t_two = ix.table_to_host()
+    assert one["num_kmers"] == two["num_kmers"] and one["total_bp"] == two["total_bp"] == 1_600_000_000
+    assert np.array_equal(one["hist256"], two["hist256"])
+    assert np.array_equal(t_one, t_two)
+    single = gpu.count_fasta(data, 15)
+    assert one["num_kmers"] == 2 * single["num_kmers"]
+    assert np.array_equal(t_one, np.minimum(2 * single["table"].astype(np.uint16), 255).astype(np.uint8))
+
+
 def test_full_config2_k15(gpu, manifest):
     """config 2: the ~800 Mbp synthetic genome at k=15, bit-exact against the reference's own run when
     that golden exists (G6, ~1 h of reference time), and through size-independent properties always."""

@@ -351,11 +351,10 @@ def test_cli_spawn_ranks_relays_failures(tmp_path, monkeypatch):
                       "open(os.path.join(os.path.dirname(__file__), 'seen_' + os.environ['RANK']), 'w').write(' '.join(["
                       "os.environ['WORLD_SIZE'], os.environ['LOCAL_RANK'], os.environ['MASTER_ADDR']] + sys.argv[1:]))\n"
                       "sys.exit(3 if os.environ['RANK'] == '1' and 'fail' in sys.argv else 0)\n")
-    monkeypatch.setattr(sys, "argv", [str(script)])
-    assert merger.spawn_ranks(3, ["a", "b"]) == 0
+    assert merger.spawn_ranks(3, ["a", "b"], script=str(script)) == 0
     assert sorted(p.name for p in tmp_path.glob("seen_*")) == ["seen_0", "seen_1", "seen_2"]
     assert (tmp_path / "seen_2").read_text() == "3 2 127.0.0.1 a b"
-    assert merger.spawn_ranks(2, ["fail"]) == 3
+    assert merger.spawn_ranks(2, ["fail"], script=str(script)) == 3
 
 
 def test_address_slices_cover_range():
