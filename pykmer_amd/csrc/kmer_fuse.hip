@@ -282,29 +282,12 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
                 return e & ~xr & hasmask;
             };
             const uint32_t x1 = has_x | (has_x << 1), x2 = x1 | (x1 << 1), x3 = x2 | (x2 << 1);   // restart smear over k-1+p positions
-#ifndef PK_REP_EARLY
-#define PK_REP_EARLY 0
-#endif
-            uint32_t d1 = 0, d2 = 0, d3 = 0;
-            // PK_REP_EARLY: a k-mer can only repeat with period p where at least 8 consecutive bases equal the base p before
-            // them.  That test is the first half of repeats(); where no lane of the wave passes it for any period -- nearly
-            // every wave on text that is not a tandem array -- the second half (the AND over k shifted copies, the gather of
-            // the even bits, the masks) is skipped by a wave-uniform branch.
-            bool look = true;
-            if (PK_REP_EARLY) {
-                auto run8 = [&](uint32_t p) -> unsigned long long {
-                    const unsigned long long x = B64 ^ ((B64 << (2u * p)) | (pp >> (32u - 2u * p)));
-                    const unsigned long long m = ~(x | (x >> 1)) & 0x5555555555555555ull;
-                    const unsigned long long a1 = m & (m << 2), a2 = a1 & (a1 << 4);
-                    return a2 & (a2 << 8);
-                };
-                look = __any((run8(1) | run8(2) | run8(3)) != 0ull);
-            }
-            if (look) {
-                d1 = repeats(1, x1 >> 16);
-                d2 = repeats(2, x2 >> 16) & ~d1;
-                d3 = repeats(3, x3 >> 16) & ~d1 & ~d2;
-            }
+            // (Measured and kept out, twice: a wave-uniform early-out of these three tests -- first with their own first half
+            // as the pre-test, 1.284 -> 1.300 ms; then with an 8-run test on the 32-bit code words, once per thread and
+            // tile, a tenth of their instructions: 1.349 -> 1.351 ms, k = 17 2.01 -> 2.08.  The tests are not what the kernel waits for.)
+            const uint32_t d1 = repeats(1, x1 >> 16);
+            const uint32_t d2 = repeats(2, x2 >> 16) & ~d1;
+            const uint32_t d3 = repeats(3, x3 >> 16) & ~d1 & ~d2;
             const uint32_t dup = d1 | d2 | d3;
             uint32_t emit = hasmask & ~dup, in_slice = 0;
 #pragma unroll
