@@ -141,7 +141,13 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
     bool ok_n = false;
     if (i_lo < i_hi) { ok_n = locate(i_lo, c_n, t_n); if (ok_n) fetch(c_n, t_n, nxt); }
     settle();
+#ifdef PK_PHASE_PROF
+    unsigned long long phase_prof[5] = {0, 0, 0, 0, 0};                   // thread 0: assembly, count, scan, park, store (cycles)
+#endif
     for (uint32_t it = i_lo; it < i_hi; it += i_step) {
+#ifdef PK_PHASE_PROF
+        const unsigned long long tile_t0 = __builtin_readcyclecounter();
+#endif
         const Fetched me = nxt;
         const uint32_t c = c_n;
         const bool ok = ok_n;
@@ -347,8 +353,16 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
         }
         // 32-bit k-mers with a second level to come: 3-byte records in two planes (part_common.h)
         uint8_t *out_hi = (!WIDE && !out16) ? reinterpret_cast<uint8_t *>(out) + level1_hi_plane_offset(pl.capacity1) : nullptr;
-        scatter_tile<KT, WIDE, NT, PER, NB, false, PK_PB_L1, (WIDE ? 0 : PK_SB_L1), !WIDE>(L, r, okm, ~0u, shift, B, low_mask, out16, out, settle, cursor1, cap_end, dump, flags, out_hi);
-        if (hot.used >= HS / 2) hot_flush(hot, side, side_n, side_cap);   // uniform: read after the barrier that ends the tile
+#ifdef PK_PHASE_PROF
+        unsigned long long *prof = phase_prof;
+        if (threadIdx.x == 0) { const unsigned long long pn = __builtin_readcyclecounter(); prof[0] += pn - tile_t0; }
+#else
+        unsigned long long *prof = nullptr;
+#endif
+        bool hot_full = false;                                            // uniform: see scatter_tile (`watch`)
+        scatter_tile<KT, WIDE, NT, PER, NB, false, PK_PB_L1, (WIDE ? 0 : PK_SB_L1), !WIDE>(L, r, okm, ~0u, shift, B, low_mask, out16, out, settle, cursor1, cap_end, dump, flags, out_hi, prof,
+                                                                                          &hot.used, HS / 2, &hot_full);
+        if (hot_full) hot_flush(hot, side, side_n, side_cap);             // (starts and ends with a barrier of its own)
     }
     if (COUNT) {
         __syncthreads();
@@ -356,6 +370,10 @@ __global__ __launch_bounds__(NT, 4) void k_walk_sort(const uint32_t *__restrict_
         return;
     }
     hot_flush(hot, side, side_n, side_cap);
+#ifdef PK_PHASE_PROF
+    if (threadIdx.x == 0)                                                  // behind side_n (u64) and the flags: words 4.. of the 256-byte flag area
+        for (int i = 0; i < 5; i++) atomicAdd(side_n + 4 + i, phase_prof[i]);
+#endif
 }
 
 // ------------------------------------------------------------------ bucket layout ---------------
@@ -382,18 +400,6 @@ __device__ __forceinline__ uint32_t room_for(unsigned long long h, double scale,
     if (stride == 1) return (uint32_t)h;
     const unsigned long long est = (unsigned long long)((double)h * scale) + 1ull;       // h < 2^32, scale <= 16: exact enough, and deterministic
     return (uint32_t)(est + est / 8 + slack);
-}
-
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-    // DPP: shifts inside the rows of 16 lanes, then the row totals broadcast into the rows behind them (no LDS traffic;
-    // the shuffle form went through ds_bpermute six times per scan, 64 scans per wave in k_provision)
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);    // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);    // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);    // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);    // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1, 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2, 3
-    return v;
 }
 
 // Final buckets are laid out by waves: wave w owns the tallies [w * seg, (w + 1) * seg), seg a multiple of 64, and

@@ -113,6 +113,18 @@ __host__ __device__ __forceinline__ size_t level1_hi_plane_offset(uint64_t capac
     return (((size_t)(capacity1 + TILE + 64) * 2u) + 255u) & ~(size_t)255u;
 }
 
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    // DPP: shifts inside the rows of 16 lanes, then the row totals broadcast into the rows behind them (no LDS traffic;
+    // the shuffle form went through ds_bpermute six times per scan, 64 scans per wave in k_provision)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // ------------------------------------------------------------------ K2 / K5: scatter ------------
 // One tile = up to 16384 records: rank within digit by LDS atomic, exclusive scan of the digit
 // counts, records + digits parked in LDS in sorted order, then written as coalesced runs at
@@ -163,8 +175,18 @@ template <typename RIN, bool WIDE, int NT = SC_T, int PER = SC_PER, int NB = 512
 __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[PER], uint32_t okm, uint32_t n_tile,
                                              uint32_t shift, uint32_t B, uint32_t low_mask, bool out16, void *__restrict__ out,
                                              Settle &&settle, uint32_t *claim = nullptr, const uint32_t *__restrict__ cap_end = nullptr,
-                                             uint32_t dump = 0, uint32_t *overflow = nullptr, uint8_t *__restrict__ out_hi = nullptr) {
+                                             uint32_t dump = 0, uint32_t *overflow = nullptr, uint8_t *__restrict__ out_hi = nullptr,
+                                             unsigned long long *prof = nullptr, const uint32_t *watch = nullptr, uint32_t watch_limit = 0,
+                                             bool *watch_hit = nullptr) {
     static_assert(NT * PER == TILE, "tile shape");
+    // PK_PHASE_PROF (experiment builds): thread 0 adds the cycles of this tile's phases -- count, scan, park, store, each up to
+    // its closing barrier -- to prof[1..4]
+#ifdef PK_PHASE_PROF
+    unsigned long long pt = __builtin_readcyclecounter();
+#define PK_PROF_MARK(i) do { if (prof && threadIdx.x == 0) { const unsigned long long pn = __builtin_readcyclecounter(); prof[i] += pn - pt; pt = pn; } } while (0)
+#else
+#define PK_PROF_MARK(i) do { } while (0)
+#endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t dbits = (uint32_t)__builtin_ctz(B);
     auto digit_of = [&](const RIN &x) -> uint32_t {
@@ -200,13 +222,17 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     }
     if (!FULL && threadIdx.x < 64u) L.off[NB + threadIdx.x] = (uint32_t)TILE + threadIdx.x;   // where empty slots park (adds of zero)
     __syncthreads();
+    PK_PROF_MARK(1);
+    // `watch` (the hot-key table's fill): looked at by ONE thread between the tile's first two barriers -- nothing writes it
+    // there -- and handed to all behind the second, so the caller's decision to flush is uniform although no barrier
+    // closes the tile any more
+    if (watch && threadIdx.x == 0) L.pad_[0] = *watch >= watch_limit ? 1u : 0u;
     // exclusive scan of hist[0..B) by the first B threads (B <= NB <= NT)
-    uint32_t my_off = 0, claimed = 0;
+    uint32_t my_off = 0, claimed = 0, room_end = 0, run_len = 0;
     {
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        uint32_t v = threadIdx.x < B ? L.hist[threadIdx.x] : 0u, inc = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        const uint32_t v = threadIdx.x < B ? L.hist[threadIdx.x] : 0u;
+        const uint32_t inc = wave_incl_scan_u32(v);          // DPP: no trips through the LDS crossbar (six ds_bpermute before)
         if (lane == 63) L.wsum[w] = inc;
         __syncthreads();
         uint32_t pre = 0;
@@ -218,16 +244,19 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
             // a claimed run start is only needed when the runs are written: the atomic's round trip to HBM
             // overlaps the parking of the records below
             if (claim) {
+                // issued here, looked at only after the parking below (the room check included: testing the returned
+                // value on the spot put the atomic's whole round trip to the memory side -- a third of this phase, 12 %
+                // of a tile -- in front of the barrier, with the other six waves waiting there)
                 claimed = v ? atomicAdd(&claim[threadIdx.x], v) : 0u;
-                if (cap_end && v && claimed + v > cap_end[threadIdx.x]) {     // provisioned room exhausted (rare): park the run aside
-                    *overflow = 1u;
-                    claimed = dump + my_off;
-                }
+                if (cap_end) room_end = cap_end[threadIdx.x];
+                run_len = v;
             } else { L.gbase[threadIdx.x] = L.run[threadIdx.x] - my_off; L.run[threadIdx.x] += v; }
             L.hist[threadIdx.x] = 0;                          // ready for the next tile
         }
     }
     __syncthreads();
+    PK_PROF_MARK(2);
+    if (watch_hit) *watch_hit = L.pad_[0] != 0u;
     if (n_tile == ~0u) n_tile = L.total;
     if (PK_UFULL) n_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_tile);   // uniform by construction; now in a scalar register
     // Parking.  PB == 0: record by record (returning add, then the write it places); every add is waited for on the spot
@@ -273,8 +302,15 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
             }
         }
     }
-    if (claim && threadIdx.x < B) L.gbase[threadIdx.x] = claimed - my_off;   // sorted position p of digit d goes to p + gbase[d]
+    if (claim && threadIdx.x < B) {
+        if (cap_end && run_len && claimed + run_len > room_end) {            // provisioned room exhausted (rare): park the run aside
+            *overflow = 1u;
+            claimed = dump + my_off;
+        }
+        L.gbase[threadIdx.x] = claimed - my_off;                             // sorted position p of digit d goes to p + gbase[d]
+    }
     __syncthreads();
+    PK_PROF_MARK(3);
     settle();
     // Run write-out, one record per lane and store: 64 consecutive sorted positions are 64 consecutive records of a run
     // (or of two).  32-bit records keep what they had above `low_mask` (narrow: the digit; wide: nothing) -- every
@@ -346,7 +382,17 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     };
     if (out16 || out_hi) store_runs(reinterpret_cast<uint16_t *>(out));
     else store_runs(reinterpret_cast<uint32_t *>(out));
-    __syncthreads();
+    // No barrier here (round 3).  What the next tile touches before ITS first barrier -- its records in registers, the
+    // digit counters (zeroed during this tile's scan, not read since), the scratch entries of `off` -- is not read by a
+    // wave still storing this tile's runs; everything else of the next tile (scan: off / gbase / total; parking: rec / dig)
+    // lies behind that barrier, which no wave passes before all have left this store loop.  Waves that are done start
+    // assembling the next tile's k-mers while the slowest still stores: thread 0 spent 31 % of a tile waiting at the
+    // first barrier for the slowest wave's assembly.
+#ifndef PK_TAIL_BARRIER
+#define PK_TAIL_BARRIER 0
+#endif
+    if (PK_TAIL_BARRIER) __syncthreads();
+    PK_PROF_MARK(4);
 }
 
 
