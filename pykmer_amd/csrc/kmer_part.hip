@@ -238,6 +238,9 @@ __global__ __launch_bounds__(NT, 4) void k_scatter2(const uint32_t *__restrict__
     const uint32_t low_mask = (1u << shift) - 1u;
     for (uint32_t i = threadIdx.x; i < 512; i += NT) { L.hist[i] = 0; L.run[i] = 0; }
     __syncthreads();
+#ifdef PK_PHASE_PROF
+    unsigned long long phase_prof[5] = {0, 0, 0, 0, 0};                   // thread 0: unpack, count, scan, park, store (cycles)
+#endif
     // records [lo, hi) of level-1 bucket b: 16-byte aligned windows of TILE records, the first / last partly masked.
     // The next window's loads are issued before the current tile is sorted, so they fly during its barriers.
     typedef uint32_t Quad __attribute__((ext_vector_type(4)));
@@ -270,6 +273,9 @@ __global__ __launch_bounds__(NT, 4) void k_scatter2(const uint32_t *__restrict__
         fetch(lo & ~3u, nxt);
         settle();
         for (uint32_t win = lo & ~3u; win < hi; win += TILE) {
+#ifdef PK_PHASE_PROF
+            const unsigned long long tile_t0 = __builtin_readcyclecounter();
+#endif
             const uint32_t v_lo = max(lo, win), v_hi = min(hi, win + (uint32_t)TILE);
             const uint32_t n_tile = v_hi - v_lo;
             uint32_t r[PER];
@@ -295,8 +301,14 @@ __global__ __launch_bounds__(NT, 4) void k_scatter2(const uint32_t *__restrict__
             if (win + TILE < hi) fetch(win + TILE, nxt);
             uint32_t *cl = CLAIM ? cursor + (uint64_t)b * B : nullptr;
             const uint32_t *ce = CLAIM ? cap_end + (uint64_t)b * B : nullptr;
-            if (full) scatter_tile<uint32_t, false, NT, PER, 512, true, PK_PB_L2, PK_SB_L2, REC24>(L, r, 0u, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
-            else scatter_tile<uint32_t, false, NT, PER, 512, false, PK_PB_L2, PK_SB_L2, REC24>(L, r, okm, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags);
+#ifdef PK_PHASE_PROF
+            if (threadIdx.x == 0) phase_prof[0] += __builtin_readcyclecounter() - tile_t0;
+            unsigned long long *prof = phase_prof;
+#else
+            unsigned long long *prof = nullptr;
+#endif
+            if (full) scatter_tile<uint32_t, false, NT, PER, 512, true, PK_PB_L2, PK_SB_L2, REC24>(L, r, 0u, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags, nullptr, prof);
+            else scatter_tile<uint32_t, false, NT, PER, 512, false, PK_PB_L2, PK_SB_L2, REC24>(L, r, okm, n_tile, shift, B, low_mask, true, out, settle, cl, ce, dump, flags, nullptr, prof);
         }
     };
     if (!CLAIM) {
@@ -320,6 +332,10 @@ __global__ __launch_bounds__(NT, 4) void k_scatter2(const uint32_t *__restrict__
         const uint64_t e = min(s + pl.R2, (uint64_t)bucket_end[b]);
         item(b, (uint32_t)s, (uint32_t)e);
     }
+#ifdef PK_PHASE_PROF
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 5; i++) atomicAdd(reinterpret_cast<unsigned long long *>(flags) - 1 + 9 + i, phase_prof[i]);   // behind the level-1 kernel's five
+#endif
 }
 
 // ------------------------------------------------------------------ K6: count in LDS ------------

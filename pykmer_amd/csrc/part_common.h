@@ -312,6 +312,9 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     __syncthreads();
     PK_PROF_MARK(3);
     settle();
+#ifdef PK_PHASE_PROF
+    if (prof && threadIdx.x == 0) { const unsigned long long pn = __builtin_readcyclecounter(); prof[0] += pn - pt; pt = pn; }   // (delivery of the next tile's loads: booked on phase 0)
+#endif
     // Run write-out, one record per lane and store: 64 consecutive sorted positions are 64 consecutive records of a run
     // (or of two).  32-bit records keep what they had above `low_mask` (narrow: the digit; wide: nothing) -- every
     // reader of 32-bit records masks for itself.  (Storing neighbours pairwise as 8 bytes, as round 1 did, halves the

@@ -443,9 +443,10 @@ static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
         time_reset(ix);
 #ifdef PK_PHASE_PROF
         {   // experiment builds: cycles thread 0 of every level-1 workgroup spent per phase, summed over workgroups and tiles
-            unsigned long long pp[5];
+            unsigned long long pp[10];
             HIPCHK(hipMemcpy(pp, flag_words + 8, sizeof pp, hipMemcpyDeviceToHost));
             fprintf(stderr, "[phase prof] k_walk_sort assembly %llu count %llu scan %llu park %llu store %llu (cycles, all workgroups)\n", pp[0], pp[1], pp[2], pp[3], pp[4]);
+            fprintf(stderr, "[phase prof] k_scatter2  unpack   %llu count %llu scan %llu park %llu store %llu\n", pp[5], pp[6], pp[7], pp[8], pp[9]);
         }
 #endif
         if (!got[0]) { ix->recounted += got[1]; break; }
