@@ -225,6 +225,8 @@ __global__ __launch_bounds__(1024) void k_starts2(uint32_t n_final, const uint32
 // NT threads x PER records = one tile.  The CLAIM launch runs as 512 x 32: two workgroups share a CU (72 KiB of LDS and
 // 128 registers each), so one sorts while the other waits at a barrier or for its stores.
 // REC24: the level-1 records are 3-byte records in two planes (32-bit k-mers; part_common.h), `in` is the 16-bit plane.
+// (Measured and kept out: the claiming launch as 1024 x 16 at 64 registers -- two workgroups = 32 waves per CU instead of 16:
+// 1.14 -> 1.19 ms with write-out batches of four, 2.1 ms with eight (46 spilled registers).)
 template <bool CLAIM, int NT, int PER, bool REC24 = false>
 __global__ __launch_bounds__(NT, 4) void k_scatter2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ wg2_start,
                                                    const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ bucket_end,
