@@ -150,14 +150,22 @@ __device__ __forceinline__ L2 shfl_up_l2(const L2 &v, int d) {
     return o;
 }
 __device__ __forceinline__ L2 wave_incl_scan_l2(L2 v, int lane, uint32_t km1) {
-    // Plain sequence text: every lane's piece restarts the window by itself (F_BRK: a break inside it, or >= k-1
-    // valid bases at its end), opens no record and leaves no pending blanks.  Then a prefix ending in lane i is
-    // lane i's own summary, except that F_FRONT is inherited from the leftmost piece (l2_compose keeps a's):
-    // no shuffles, no composition.
+    // Plain sequence text and header lines: every lane's piece restarts the window by itself (F_BRK: a break inside it,
+    // or >= k-1 valid bases at its end) and leaves no pending blanks.  Then a prefix ending in lane i is lane i's own
+    // summary, except that F_FRONT is inherited from the leftmost piece (l2_compose keeps a's) and the records opened
+    // add up: no composition, and shuffles only in a wave that opens a record (a read set: every wave, and the
+    // six-step composition was a fifth of the structure pass there).
     const uint32_t want = F_NONID | F_PRESET | F_BRK;
-    if (__all((v.flags & want) == want && v.rec == 0u && v.p_tail == 0ull)) {
+    if (__all((v.flags & want) == want && v.p_tail == 0ull)) {
         const uint32_t front0 = (uint32_t)__builtin_amdgcn_readlane((int)v.flags, 0) & F_FRONT;
         v.flags = (v.flags & ~F_FRONT) | front0;
+        if (__any(v.rec != 0u)) {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(v.rec, d, 64);
+                if (lane >= d) v.rec += o;
+            }
+        }
         return v;
     }
 #pragma unroll
@@ -195,12 +203,15 @@ __device__ __forceinline__ L2 wg_excl_scan_l2(const L2 &mine, const L2 &seed, L2
     // compose to "the last one, with the first one's F_FRONT"
     const uint32_t want = F_NONID | F_PRESET | F_BRK;
     bool plain = !(seed.flags & F_NONID);
-    for (int i = 0; i < WG / 64; i++) plain = plain && (sh[i].flags & want) == want && sh[i].rec == 0u && sh[i].p_tail == 0ull;
+    for (int i = 0; i < WG / 64; i++) plain = plain && (sh[i].flags & want) == want && sh[i].p_tail == 0ull;
     if (plain) {                                                         // uniform: sh[] is the same for every lane
         const uint32_t front0 = sh[0].flags & F_FRONT;
-        if (w > 0) { pre = sh[w - 1]; pre.flags = (pre.flags & ~F_FRONT) | front0; }
+        uint32_t rec_before = 0, rec_all = 0;
+        for (int i = 0; i < WG / 64; i++) { if (i < w) rec_before += sh[i].rec; rec_all += sh[i].rec; }
+        if (w > 0) { pre = sh[w - 1]; pre.flags = (pre.flags & ~F_FRONT) | front0; pre.rec = rec_before; }
         tot = sh[WG / 64 - 1];
         tot.flags = (tot.flags & ~F_FRONT) | front0;
+        tot.rec = rec_all;
     } else {
         for (int i = 0; i < w; i++) pre = l2_compose(pre, sh[i], km1);
         tot = pre;
@@ -488,8 +499,16 @@ __device__ __forceinline__ unsigned long long header_text(const PieceMasks &m, u
     const unsigned long long x = ~m.term;
     return ((x + starts) ^ x) & x;
 }
-// no line of the piece begins with a blank or control byte (then the L1 summary needs no byte-wise walk)
-__device__ __forceinline__ bool lines_start_plain(const PieceMasks &m) { return (((m.term << 1) | 1ull) & m.blank) == 0ull; }
+// No line that BEGINS in the piece begins with a blank or control byte: then the L1 summary needs no byte-wise walk, and
+// header lines are the lines whose first byte is '>'.  A blank as the piece's first byte is fine if a terminator follows
+// somewhere (the summary is then decided behind the last terminator) -- it only matters when the piece turns out to be
+// entered at a line start, which first_byte_plain() rules out once the line state is known.  (A header line with words in
+// it crosses a piece seam at a blank in one case out of ten: a read set had such a piece in most of its chunks, and one
+// piece for the byte-wise machine costs the workgroup as much as sixty-four.)
+__device__ __forceinline__ bool lines_start_plain(const PieceMasks &m) {
+    return ((m.term << 1) & m.blank) == 0ull && (!(m.blank & 1ull) || m.term != 0ull);
+}
+__device__ __forceinline__ bool first_byte_plain(const PieceMasks &m, uint32_t ls_in) { return !(m.blank & 1ull) || ls_in != LS_START; }
 
 // L1 summary from the masks of a FULL piece with lines_start_plain(): the state after the last terminator is START; what
 // follows it is a header line if it begins with '>' and sequence text otherwise; blanks further in change nothing.

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(WG, PK_LB_L2) void k_chunk_l2(const uint8_t *__rest
     unsigned long long H = 0;
     if (__any(!clean && masks1)) {
         H = header_text(pm, ls_in);
-        header_piece = !clean && masks1 && (pm.blank & ~H) == 0ull;
+        header_piece = !clean && masks1 && first_byte_plain(pm, ls_in) && (pm.blank & ~H) == 0ull;
     }
     L2 my2 = l2_identity();
     if (clean) my2 = l2_of_clean_piece(pm, pk, nb, ls_in, km1);

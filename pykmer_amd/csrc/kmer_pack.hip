@@ -56,6 +56,30 @@ __device__ __forceinline__ void lds_or_bits(uint32_t *dst, uint32_t at, unsigned
     }
 }
 
+// The valid windows that END at each of a piece's nv pushed-together bases (bit j: one ends at base j), given the bases'
+// restart bits as the piece alone knows them (F; base 0's is completed here: the run was already broken when the piece
+// began) and the length of the run carried in: no restart among the k-1 positions behind the window's first base, and --
+// where no restart precedes -- enough bases carried in (indexer.py:144).
+__device__ __forceinline__ unsigned long long window_ends(unsigned long long &F, uint32_t nv, uint32_t run, uint32_t km1) {
+    if (run == 0u && nv) F |= 1ull;
+    const unsigned long long keep = nv >= 64u ? ~0ull : ((1ull << nv) - 1ull);
+    unsigned long long X = 0;
+    {
+        const unsigned long long y1 = F | (F << 1), y2 = y1 | (y1 << 2), y3 = y2 | (y2 << 4), y4 = y3 | (y3 << 8);
+        uint32_t off = 0;                                                 // k - 1 <= 20 copies: 16 + 4 at most
+        if (km1 & 16u) { X |= y4; off = 16; }
+        if (km1 & 8u) { X |= y3 << off; off += 8; }
+        if (km1 & 4u) { X |= y2 << off; off += 4; }
+        if (km1 & 2u) { X |= y1 << off; off += 2; }
+        if (km1 & 1u) { X |= F << off; }
+    }
+    const uint32_t short_by = run >= km1 ? 0u : km1 - run;                // leading positions the carried run cannot complete
+    const unsigned long long lead = short_by >= 64u ? ~0ull : ((1ull << short_by) - 1ull);
+    // a restart inside the piece takes over from the carried run: positions at or above the first restart obey X only
+    const unsigned long long below_first = F ? ((F & (0ull - F)) - 1ull) : ~0ull;
+    return ~X & ~(lead & below_first) & keep;
+}
+
 // ------------------------------------------------------------------ clean pieces ----
 // A CLEAN piece holds nothing but sequence characters and line terminators and does not start inside a header line
 // (the structure pass flags everything else): no record opens, nothing is stripped.  The structure pass has already
@@ -77,30 +101,84 @@ __device__ __forceinline__ void squeeze_apply(const PiecePack &pk, SeqWalker &wk
     }
     const bool live = mine && wk.rec != 0;                                // text before the first header is dropped
     unsigned long long F = pk.restart;
-    if (wk.run == 0u && nv) F |= 1ull;                                    // the run was already broken when the piece began
-    const unsigned long long keep = nv >= 64u ? ~0ull : ((1ull << nv) - 1ull);
-    // valid windows ending in this piece: no restart among the k-1 positions behind the window's first base, and --
-    // where no restart precedes -- enough bases carried in
-    const uint32_t km1 = wk.k - 1u;
-    unsigned long long X = 0;
-    {
-        const unsigned long long y1 = F | (F << 1), y2 = y1 | (y1 << 2), y3 = y2 | (y2 << 4), y4 = y3 | (y3 << 8);
-        uint32_t off = 0;                                                 // k - 1 <= 20 copies: 16 + 4 at most
-        if (km1 & 16u) { X |= y4; off = 16; }
-        if (km1 & 8u) { X |= y3 << off; off += 8; }
-        if (km1 & 4u) { X |= y2 << off; off += 4; }
-        if (km1 & 2u) { X |= y1 << off; off += 2; }
-        if (km1 & 1u) { X |= F << off; }
-    }
-    const uint32_t short_by = wk.run >= km1 ? 0u : km1 - wk.run;         // leading positions the carried run cannot complete
-    const unsigned long long lead = short_by >= 64u ? ~0ull : ((1ull << short_by) - 1ull);
-    // a restart inside the piece takes over from the carried run: positions at or above the first restart obey X only
-    const unsigned long long below_first = F ? ((F & (0ull - F)) - 1ull) : ~0ull;
-    const unsigned long long has = ~X & ~(lead & below_first) & keep;
+    const unsigned long long has = window_ends(F, nv, wk.run, wk.k - 1u);
     wk.kmer_acc += live ? (uint64_t)__popcll(has) : 0ull;
     pb.code_lo = live ? pk.c_lo : 0ull; pb.code_hi = live ? pk.c_hi : 0ull;
     pb.restart = live ? F : 0ull;
     pb.n = live ? nv : 0u;
+}
+
+// ------------------------------------------------------------------ header pieces ----
+// A HEADER PIECE (the structure pass's term, k_chunk_l2): a full piece that holds header text -- it opens records, or is
+// entered inside a header line -- whose lines do not begin with a blank and that has no blank or control byte outside the
+// header text.  Its header lines are found by masks (header_text, fasta_fsm.h): everything that is neither a terminator
+// nor header text is a sequence character.  A read set has such a piece every kilobase; walking them byte by byte (64
+// steps of ~100 instructions for the wave, whatever the number of lanes at work) was 86 % of this kernel's time there.
+//
+// Index one past the last byte of the header line `run` that str.strip() keeps (indexer.py:56,66), 0 if there is none:
+// bytes from 0x21 up are kept; blanks and control bytes above the last of those are looked at one by one, from the top
+// (a header rarely ends in one: zero rounds).
+__device__ __forceinline__ uint32_t header_text_end(const uint8_t *text, unsigned long long run, unsigned long long blank) {
+    const unsigned long long solid = run & ~blank;
+    uint32_t end = solid ? 64u - (uint32_t)__builtin_clzll(solid) : 0u;
+    unsigned long long todo = run & blank & (end >= 64u ? 0ull : ~0ull << end);
+    while (todo) {
+        const uint32_t p = 63u - (uint32_t)__builtin_clzll(todo);
+        if (!is_ws(text[p])) { end = p + 1u; break; }
+        todo ^= 1ull << p;
+    }
+    return end;
+}
+
+#ifdef PK_HP_NOINLINE
+#define PK_HP_INLINE __attribute__((noinline))
+#else
+#define PK_HP_INLINE __forceinline__
+#endif
+// All lanes of the wave; `mine`: this lane holds a header piece of a live record (wq.rec != 0) in `text`, with wq at the
+// exact state of its first byte.  Leaves the piece's bases in rb and the tallies of the piece's LAST record in wq (the
+// caller flushes them); the records that end inside the piece are flushed here.
+#ifdef PK_HP_NOINLINE
+__device__ __attribute__((noinline)) void squeeze_header_piece(const uint8_t *text, SeqWalker &wq, PieceBases &rb, bool mine);
+#endif
+__device__ PK_HP_INLINE void squeeze_header_piece(const uint8_t *text, SeqWalker &wq, PieceBases &rb, bool mine) {
+    PieceMasks pm;
+    uint32_t cw[4];
+    piece_scan(text, (uint32_t)PIECE, pm, cw);
+    const uint32_t ls_in = wq.ls;
+    const unsigned long long H = header_text(pm, ls_in), S = header_starts(pm, ls_in);
+    const unsigned long long seq = ~pm.term & ~H, valid = pm.valid & seq;
+    PiecePack hk;
+    piece_compact(mine ? valid : 0ull, mine ? ((seq & ~valid) | H) : 0ull, cw, true, 0u, false, hk);     // loops as a wave
+    if (!mine) return;
+    // blanks pending from the piece before: interior if a sequence character comes first (indexer.py:56; step())
+    if (wq.pend && ls_in == LS_SEQ && (seq & 1ull)) { wq.seq_acc += wq.pend; wq.run = 0u; }
+    wq.pend = 0;
+    unsigned long long F = hk.restart;
+    const uint32_t nv = pack_n_valid(hk);
+    const unsigned long long has = window_ends(F, nv, wq.run, wq.k - 1u);
+    if (ls_in == LS_HEADER) {                                             // the line the piece is entered in goes on
+        const uint32_t e = header_text_end(text, H & ~(H + 1ull), pm.blank);
+        if (e) wq.name_end = wq.pos0 + e;
+    }
+    // one round per record opened: what lies below its '>' belongs to the record before
+    unsigned long long below_prev = 0, cmp_prev = 0, todo = S;
+    while (todo) {
+        const uint32_t s = (uint32_t)__builtin_ctzll(todo);
+        const unsigned long long bit = 1ull << s, below = bit - 1ull;
+        const unsigned long long cmp_below = (1ull << (uint32_t)__popcll(valid & below)) - 1ull;     // <= 63 bases below a byte
+        wq.seq_acc += (uint64_t)__popcll(seq & below & ~below_prev);
+        wq.kmer_acc += (uint64_t)__popcll(has & cmp_below & ~cmp_prev);
+        wq.flush_rec();
+        wq.rec++;                                                         // indexer.py:66-82
+        if (wq.rec <= wq.recs_cap) wq.recs[wq.rec - 1].name_off = wq.pos0 + s + 1u;
+        wq.name_end = wq.pos0 + header_text_end(text, H & ~(H + bit), pm.blank);      // at least the '>' itself
+        below_prev = below; cmp_prev = cmp_below;
+        todo &= todo - 1ull;
+    }
+    wq.seq_acc += (uint64_t)__popcll(seq & ~below_prev);
+    wq.kmer_acc += (uint64_t)__popcll(has & ~cmp_prev);
+    rb.code_lo = hk.c_lo; rb.code_hi = hk.c_hi; rb.restart = F; rb.n = nv;
 }
 
 // ---- staging: the chunk's 16 KiB as a plain image in LDS (the lane's piece = 64 contiguous bytes; the 4-way bank
@@ -190,6 +268,12 @@ __global__ __launch_bounds__(WG, PK_LB_SQ) void k_squeeze(const uint8_t *__restr
     }
     settle();
     __syncthreads();
+#ifdef PK_PHASE_PROF      // where a workgroup's time goes, in cycles of its thread 0 (experiment builds; printed by pk_api.hip)
+    unsigned long long sq_prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sq_t = __builtin_readcyclecounter();
+#define SQ_MARK(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); sq_prof[i] += n_ - sq_t; sq_t = n_; } } while (0)
+#else
+#define SQ_MARK(i) do { } while (0)
+#endif
     for (uint32_t c = c_lo; c < c_hi; c++) {
         const uint64_t base = (uint64_t)c * CHUNK;
         uint8_t *buf = image[(c - c_lo) & 1u];
@@ -204,6 +288,7 @@ __global__ __launch_bounds__(WG, PK_LB_SQ) void k_squeeze(const uint8_t *__restr
             if (threadIdx.x == 0) racc.rec0 = first_rec;
             __syncthreads();
         }
+        SQ_MARK(0);                                        // image barrier + record-window move
         const Fetched me = nxt;
         if (c + 1 < c_hi) {
             // the other image is free: its readers passed the barriers of the chunk before this one
@@ -230,10 +315,12 @@ __global__ __launch_bounds__(WG, PK_LB_SQ) void k_squeeze(const uint8_t *__restr
             pk.restart = ((unsigned long long)me.p1.y << 32) | me.p1.x; pk.meta = me.p1.z; pk.pad_ = 0;
             if (all_clean || __any(clean)) squeeze_apply(pk, wk, pb, clean);
         }
+        SQ_MARK(1);                                        // state composition + clean pieces
         if (!all_clean) {
             if (!clean) queue[atomicAdd(&n_queued, 1u)] = (uint16_t)threadIdx.x;
             __syncthreads();
             const uint32_t n_q = n_queued;
+            SQ_MARK(8);
             for (uint32_t q0 = (threadIdx.x >> 6) * 64u; q0 < n_q; q0 += WG) {        // wave-uniform
                 const uint32_t qi = q0 + (threadIdx.x & 63u);
                 const bool work = qi < n_q;
@@ -242,30 +329,45 @@ __global__ __launch_bounds__(WG, PK_LB_SQ) void k_squeeze(const uint8_t *__restr
                 SeqWalker wq;
                 wq.setup(k, recs, recs_cap, &racc);
                 wq.begin(lane_state_ls(l2s), l2_compose(chunk_st, lane_state_l2(l2s), km1), stream_off + base + (uint64_t)pc * PIECE);
-                const uint32_t nbq = work ? piece_len_of(pc, base, n_bytes) : 0u;
+                // header pieces by masks (text in front of the first record is dropped: that piece takes the byte-wise walk)
+#ifdef PK_NO_HP_MASKS
+                const bool by_masks = false;
+#else
+                const bool by_masks = work && lane_state_header_piece(l2s) && wq.rec != 0u;
+#endif
+                const uint32_t nbq = (work && !by_masks) ? piece_len_of(pc, base, n_bytes) : 0u;
                 uint8_t *pq = buf + pc * PIECE;
                 PieceBases rb;
                 rb.clear();
-                for_each_byte_of(pq, nbq, [&](uint32_t i, uint32_t ch, bool act) {
-                    uint32_t code;
-                    bool rst;
-                    const bool take = wq.step(i, ch, act, code, rst);
-                    rb.push(take, code, rst);
-                });
+                SQ_MARK(9);
+                if (__any(by_masks)) squeeze_header_piece(pq, wq, rb, by_masks);
+                SQ_MARK(10);
+                if (__any(nbq != 0u))
+                    for_each_byte_of(pq, nbq, [&](uint32_t i, uint32_t ch, bool act) {
+                        uint32_t code;
+                        bool rst;
+                        const bool take = wq.step(i, ch, act, code, rst);
+                        rb.push(take, code, rst);
+                    });
+                SQ_MARK(11);
                 wq.flush_rec_wave();
+                SQ_MARK(12);
                 wk.seq_tot += wq.seq_tot; wk.kmer_tot += wq.kmer_tot;                  // stream totals travel with the lane that did the work
                 if (work) {
                     unsigned long long *res = reinterpret_cast<unsigned long long *>(pq);
                     res[0] = rb.code_lo; res[1] = rb.code_hi; res[2] = rb.restart; res[3] = rb.n;
                 }
             }
+            SQ_MARK(13);
             __syncthreads();
+            SQ_MARK(14);
             if (!clean) {
                 const unsigned long long *res = reinterpret_cast<const unsigned long long *>(piece);
                 pb.code_lo = res[0]; pb.code_hi = res[1]; pb.restart = res[2]; pb.n = (uint32_t)res[3];
             }
             if (threadIdx.x == 0) n_queued = 0;                                       // read again only after the next barrier
         }
+        SQ_MARK(2);                                        // queued pieces (+ two barriers)
         wk.flush_rec_wave();
         // where the lane's bases go in the chunk's slot: exclusive prefix of the counts over the workgroup
         uint32_t total;
@@ -273,7 +375,9 @@ __global__ __launch_bounds__(WG, PK_LB_SQ) void k_squeeze(const uint8_t *__restr
         lds_or_bits(slot_codes, 2u * at, pb.code_lo, pb.code_hi, 2u * pb.n);
         lds_or_bits(slot_rst, at, pb.restart, 0ull, pb.n);
         __syncthreads();
+        SQ_MARK(3);                                        // record tallies, scan, bit packing into the slot image
         settle();
+        SQ_MARK(4);                                        // delivery of the next chunk's loads
         // slot -> HBM, 16 bytes per lane, only the words that hold bases; the LDS copy is cleared for the next chunk
         const uint32_t code_q = (total + 63u) / 64u, rst_q = (total + 127u) / 128u;      // uint4 groups in use
         uint4 *gc = reinterpret_cast<uint4 *>(codes + (uint64_t)c * SLOT_CODE_WORDS);
@@ -287,7 +391,12 @@ __global__ __launch_bounds__(WG, PK_LB_SQ) void k_squeeze(const uint8_t *__restr
             reinterpret_cast<uint4 *>(slot_rst)[threadIdx.x] = make_uint4(0, 0, 0, 0);
         }
         if (threadIdx.x == 0) n_bases[c] = total;
+        SQ_MARK(5);                                        // slot store
     }
+#ifdef PK_PHASE_PROF
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(reinterpret_cast<unsigned long long *>(flags) - 1 + 14 + i, sq_prof[i]);
+#endif
     wk.finish();
     recacc_finish(racc, recs, recs_cap, carry);
 }
@@ -296,12 +405,12 @@ void launch_squeeze(const uint8_t *fasta, uint64_t n, uint64_t stream_off, const
                     const uint32_t *chunk_odd, uint32_t k, uint32_t n_chunks, uint32_t n_wg, uint32_t chunks_per_wg, uint32_t *codes, uint32_t *restarts, uint32_t *n_bases,
                     DevRec *recs, uint64_t recs_cap, Carry *carry, uint32_t *flags, hipStream_t s) {
     static const bool lit = !(getenv("PK_K15") && atoi(getenv("PK_K15")) == 0);
-    if (lit && k == 15) hipLaunchKernelGGL(k_squeeze<15>, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, packs, st2, chunk_odd, k, n_chunks, chunks_per_wg, codes,
-                                           restarts, n_bases, recs, recs_cap, carry, flags);
-    else if (lit && k == 17) hipLaunchKernelGGL(k_squeeze<17>, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, packs, st2, chunk_odd, k, n_chunks, chunks_per_wg, codes,
-                                                restarts, n_bases, recs, recs_cap, carry, flags);
-    else hipLaunchKernelGGL(k_squeeze<0>, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, packs, st2, chunk_odd, k, n_chunks, chunks_per_wg, codes,
-                            restarts, n_bases, recs, recs_cap, carry, flags);
+#define PK_SQUEEZE(KC) hipLaunchKernelGGL(k_squeeze<KC>, dim3(n_wg), dim3(WG), 0, s, fasta, n, stream_off, lane_state, packs, st2, chunk_odd, k, n_chunks, \
+                                          chunks_per_wg, codes, restarts, n_bases, recs, recs_cap, carry, flags)
+    if (lit && k == 15) PK_SQUEEZE(15);
+    else if (lit && k == 17) PK_SQUEEZE(17);
+    else PK_SQUEEZE(0);
+#undef PK_SQUEEZE
 }
 
 }  // namespace pk

@@ -443,10 +443,13 @@ static int feed_piece(pk_indexer *ix, const uint8_t *f, uint64_t n_bytes) {
         time_reset(ix);
 #ifdef PK_PHASE_PROF
         {   // experiment builds: cycles thread 0 of every level-1 workgroup spent per phase, summed over workgroups and tiles
-            unsigned long long pp[10];
+            unsigned long long pp[26];
             HIPCHK(hipMemcpy(pp, flag_words + 8, sizeof pp, hipMemcpyDeviceToHost));
             fprintf(stderr, "[phase prof] k_walk_sort assembly %llu count %llu scan %llu park %llu store %llu (cycles, all workgroups)\n", pp[0], pp[1], pp[2], pp[3], pp[4]);
             fprintf(stderr, "[phase prof] k_scatter2  unpack   %llu count %llu scan %llu park %llu store %llu\n", pp[5], pp[6], pp[7], pp[8], pp[9]);
+            fprintf(stderr, "[phase prof] k_squeeze   window %llu clean %llu queued %llu tally+scan+pack %llu delivery %llu store %llu\n",
+                    pp[10], pp[11], pp[12], pp[13], pp[14], pp[15]);
+            fprintf(stderr, "[phase prof]   of queued: barrier1 %llu load+begin %llu masks %llu bytes %llu flush %llu write %llu barrier2 %llu\n", pp[18], pp[19], pp[20], pp[21], pp[22], pp[23], pp[24]);
         }
 #endif
         if (!got[0]) { ix->recounted += got[1]; break; }

@@ -82,7 +82,7 @@ int launch_partitioned(const L2 *st2, uint64_t n_bytes, const PartPlan &pl, uint
                        unsigned long long *hist, unsigned long long *hist_replicas, bool armed);
 constexpr uint32_t HIST_REPLICAS = 64;   // copies of the 256-bin histogram change the bucket-count workgroups add into (zeroed by their reader, k_apply_side)
 #ifdef PK_PHASE_PROF
-constexpr uint32_t PART_FLAG_WORDS = 28;  // + twice five u64 phase-cycle counters (experiment builds)
+constexpr uint32_t PART_FLAG_WORDS = 60;  // + 5 + 5 + 8 u64 phase-cycle counters (experiment builds)
 #else
 constexpr uint32_t PART_FLAG_WORDS = 6;   // side_n (u64) + flags[4], zeroed together
 #endif

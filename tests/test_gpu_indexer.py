@@ -316,6 +316,36 @@ def test_random_structure_fuzz(gpu):
             _check_against_oracle(gpu, data, k)
 
 
+def test_read_set_headers_fuzz(gpu):
+    """Short records with every kind of header line: the squeeze pass takes pieces with header text by masks (several
+    headers in one 64-byte piece, names with blanks / control bytes / trailing whitespace, CR LF, empty records, a '>'
+    inside sequence text, text in front of the first header) and the rest byte by byte; both must agree with the oracle."""
+    rng = np.random.default_rng(2024)
+    names = [b"r", b"read_%d len=100", b"x y\tz ", b"n\x01\x02 ", b"t\x1c\x1d", b"", b" lead", b"tail   \t", b"q\x0b\x0c", b">>dbl", b"a" * 70, b"b" * 130]
+    ends = [b"\n", b"\r\n", b"\n\n", b"\r"]
+    for trial in range(5):
+        parts = [b"ACGTTTGA\nAC\n"] if trial % 2 else []                   # text before the first header is dropped
+        for i in range(int(rng.integers(200, 1500))):
+            name = names[int(rng.integers(len(names)))]
+            if b"%d" in name:
+                name = name % i
+            parts.append(b">" + name + ends[int(rng.integers(len(ends)))])
+            shape = int(rng.integers(6))
+            n = int(rng.integers(0, 4)) if shape == 0 else int(rng.integers(1, 400))
+            body = bytearray(b"ACGT"[j] for j in rng.integers(0, 4, size=n))
+            if shape == 1 and n > 4:
+                body[int(rng.integers(n))] = ord("N")
+            if shape == 2 and n > 4:
+                body[int(rng.integers(1, n))] = ord(">")                     # not at a line start: maps to None
+            width = int(rng.choice([0, 60, 61, 64, 7]))
+            if width and n:
+                body = b"\n".join(bytes(body[j:j + width]) for j in range(0, n, width))
+            parts.append(bytes(body) + ends[int(rng.integers(len(ends)))])
+        data = b"".join(parts)
+        for k in ((3, 15) if trial < 2 else (9,)):
+            _check_against_oracle(gpu, data, k)
+
+
 def test_unwrapped_long_lines_and_empty(gpu):
     rng = np.random.default_rng(3)
     seq = "".join("ACGT"[i] for i in rng.integers(0, 4, size=300_000))
