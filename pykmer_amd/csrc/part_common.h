@@ -230,7 +230,14 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
     // exclusive scan of hist[0..B) by the first B threads (B <= NB <= NT)
     uint32_t my_off = 0, claimed = 0, room_end = 0, run_len = 0;
     {
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        // The thread index is made opaque to the compiler here.  What this block derives from it -- the wave's slot in
+        // wsum, the thread's entries of claim and cap_end -- is invariant across the caller's tile loop; the compiler kept
+        // those three addresses in registers, spilled them under pressure (k_scatter2: 9 registers), and every re-load
+        // from scratch is followed by a wait for ALL vector memory operations in flight: the next tile's records,
+        // requested before this tile and meant to arrive during it (settle), were waited for here, between two barriers.
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, w = tid >> 6;
         const uint32_t v = threadIdx.x < B ? L.hist[threadIdx.x] : 0u;
         const uint32_t inc = wave_incl_scan_u32(v);          // DPP: no trips through the LDS crossbar (six ds_bpermute before)
         if (lane == 63) L.wsum[w] = inc;
@@ -247,8 +254,8 @@ __device__ __forceinline__ void scatter_tile(ScatterLdsT<NB> &L, const RIN (&r)[
                 // issued here, looked at only after the parking below (the room check included: testing the returned
                 // value on the spot put the atomic's whole round trip to the memory side -- a third of this phase, 12 %
                 // of a tile -- in front of the barrier, with the other six waves waiting there)
-                claimed = v ? atomicAdd(&claim[threadIdx.x], v) : 0u;
-                if (cap_end) room_end = cap_end[threadIdx.x];
+                claimed = v ? atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(claim) + tid * 4u), v) : 0u;
+                if (cap_end) room_end = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(cap_end) + tid * 4u);
                 run_len = v;
             } else { L.gbase[threadIdx.x] = L.run[threadIdx.x] - my_off; L.run[threadIdx.x] += v; }
             L.hist[threadIdx.x] = 0;                          // ready for the next tile
