@@ -297,7 +297,9 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT == 51
     for (int m = 0; m < ITEMS; m++) {
         const int q = threadIdx.x + m * nthreads;
         const int t = __builtin_amdgcn_readfirstlane(q / TW);
-        tab[m] = t < N ? tables[t] : nullptr;                  // t < N implies q < items; all of it wave-uniform
+        const uint64_t pv = reinterpret_cast<uint64_t>(t < N ? tables[t] : nullptr);       // t < N implies q < items; all of it wave-uniform
+        tab[m] = reinterpret_cast<const uint8_t *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pv >> 32)) << 32) |
+                                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv));   // ... and told so: scalar registers
     }
     auto fetch_item = [&](uint64_t tile, int m) {
         const int q = threadIdx.x + m * nthreads;
@@ -307,9 +309,14 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT == 51
         if (byte0 + (uint64_t)(RMAX * 2048) <= n) {                        // uniform: nearly every tile
             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
             typedef const __attribute__((address_space(1))) u32x4 *gptr;   // global, not flat: see load_half
+            // scalar base + a 32-bit lane offset formed HERE: as a loop invariant "table + lane offset" was a register pair
+            // per item, spilled in the 24-table shape, and its re-load from scratch waits for every load in flight -- the
+            // prefetch of the items before it
             const uint8_t *base = tab[m] + byte0;
-            const u32x4 x = __builtin_nontemporal_load((gptr)(base + voff));
-            const u32x4 y = __builtin_nontemporal_load((gptr)(base + voff + 1024u));
+            uint32_t vo = voff;
+            asm volatile("" : "+v"(vo));
+            const u32x4 x = __builtin_nontemporal_load((gptr)(base + vo));
+            const u32x4 y = __builtin_nontemporal_load((gptr)((base + vo) + 1024u));
             ra[m] = make_uint4(x.x, x.y, x.z, x.w); rb[m] = make_uint4(y.x, y.y, y.z, y.w);
         } else {
             const uint64_t w0 = tile * TW;
