@@ -9,7 +9,7 @@ O=gpurun_out/profile_round
 mkdir -p $O
 timeout -k 10 600 python bench.py > $O/bench.json
 echo "bench done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o ks -- python3 bench.py --steps 5 --warmup 1 --no-cpu --no-merge --no-e2e > $O/bench_under_rocprof.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o ks -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-merge --no-e2e > $O/bench_under_rocprof.json
 echo "stats done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o fetch -- python3 bench.py --steps 2 --warmup 0 --no-cpu --no-e2e > $O/pmc_fetch.log
 echo "fetch done"
@@ -17,9 +17,9 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 echo "write done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_k17 -o fetch -- python3 bench.py --k 17 --steps 2 --warmup 0 --no-cpu --no-merge --no-e2e > $O/pmc_fetch_k17.log
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_k17 -o write -- python3 bench.py --k 17 --steps 2 --warmup 0 --no-cpu --no-merge --no-e2e > $O/pmc_write_k17.log
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_k17 -o ks -- python3 bench.py --k 17 --steps 5 --warmup 1 --no-cpu --no-merge --no-e2e > $O/bench_k17_under_rocprof.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_k17 -o ks -- python3 bench.py --k 17 --steps 10 --warmup 3 --no-cpu --no-merge --no-e2e > $O/bench_k17_under_rocprof.json
 echo "k17 passes done"
-timeout -k 10 300 python bench.py --k 17 --no-merge --no-cpu --no-e2e --steps 5 --warmup 1 > $O/bench_k17.json
+timeout -k 10 300 python bench.py --k 17 --no-merge --no-cpu --no-e2e --steps 10 --warmup 3 > $O/bench_k17.json
 PK_TMP=/dev/shm timeout -k 10 400 python tools/e2e_cli.py > $O/e2e_cli.json
 timeout -k 10 300 python tools/profile_mix.py > $O/profile_mix.txt 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq -o sq -- python3 bench.py --steps 2 --warmup 0 --no-cpu --no-merge --no-e2e > $O/pmc_sq.log
