@@ -340,8 +340,9 @@ __device__ __forceinline__ L2 piece_l2_at(const uint8_t *mine, uint32_t nb, uint
 // character that maps to None lay between it and the base before, indexer.py:36-41,144) and three counts.  The squeeze
 // pass then reads these 32 bytes instead of the 64 bytes of text -- it only adds what depends on the parser state the
 // piece is entered with.  (Until the middle of round 2 both passes classified the text: 35 vector instructions per byte
-// between them, three quarters of it the same SWAR tests twice.)  Pieces that need the byte-wise machine (a header, a
-// blank, a control byte; or entered inside a header line) carry a record too, but it is not used.
+// between them, three quarters of it the same SWAR tests twice.)  Pieces that are not clean (header text, a blank, a
+// control byte; or entered inside a header line) carry a record too, but it is not used: the squeeze pass goes back to
+// their text.
 struct PiecePack {
     unsigned long long c_lo, c_hi;     // codes of bases 0-31, 32-63
     unsigned long long restart;        // bit j: base j restarts the run -- without what the incoming state adds at base 0

@@ -76,9 +76,10 @@ __global__ __launch_bounds__(WG) void k_chunk_l1(const uint8_t *__restrict__ fas
 // Every piece is classified once (classify_piece, fasta_fsm.h): which bytes are bases, terminators, or something only the
 // byte-wise machine understands; the bases' codes pushed together; their restart bits.  The L1 / L2 summaries of a piece
 // of plain sequence text come from those masks, and the pack is handed to the squeeze pass, which does not read the text
-// of such pieces again.  Pieces with a header, a blank or a control byte -- or that start inside a header line -- need the
-// byte-wise machines, which cost a wave the same for one lane as for 64: those pieces are queued and worked off 64 per
-// wave pass (a read set has a header every kilobase; each wave then held a few such pieces and every wave took both machines).
+// of such pieces again.  Pieces with header text whose lines begin plainly (header pieces) get their summaries from masks
+// too (header_text).  What is left -- a blank or control byte outside header text, a line that begins with one, the partial
+// last piece -- needs the byte-wise machines, which cost a wave the same for one lane as for 64: those pieces are queued
+// and worked off 64 per wave pass.
 __global__ __launch_bounds__(WG, PK_LB_L2) void k_chunk_l2(const uint8_t *__restrict__ fasta, uint64_t n_bytes,
                                                  const L1 *__restrict__ chunk_l1_state, L2 *__restrict__ chunk_l2,
                                                  LaneState *__restrict__ lane_state, PiecePack *__restrict__ packs,

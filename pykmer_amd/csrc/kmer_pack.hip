@@ -234,11 +234,11 @@ __global__ __launch_bounds__(WG, PK_LB_SQ) void k_squeeze(const uint8_t *__restr
         if (blockIdx.x == 0 && threadIdx.x == 0) flags[0] = 2u;
         return;
     }
-    __shared__ __attribute__((aligned(16))) uint8_t image[2][CHUNK];   // text of chunks that hold pieces for the byte-wise machine
+    __shared__ __attribute__((aligned(16))) uint8_t image[2][CHUNK];   // text of chunks that hold queued pieces (header pieces, pieces for the byte-wise machine)
     __shared__ __attribute__((aligned(16))) uint32_t slot_codes[SLOT_CODE_WORDS + 8];   // + slack: lds_or_bits touches up to 5 words
     __shared__ __attribute__((aligned(16))) uint32_t slot_rst[SLOT_RST_WORDS + 8];
     __shared__ uint32_t scan_sh[WG / 64];
-    __shared__ uint16_t queue[WG];                         // pieces that need the byte-wise machine
+    __shared__ uint16_t queue[WG];                         // pieces that need their text
     __shared__ uint32_t n_queued;
     __shared__ RecAcc racc;
     const uint32_t k = KC ? KC : k_arg, km1 = k - 1;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(WG, PK_LB_SQ) void k_squeeze(const uint8_t *__restr
     // Per chunk a lane needs its state (8 bytes) and its pack (32 bytes).  Both are requested one chunk AHEAD and taken
     // delivery of right before the current chunk's slot is stored (settle, as in the sort kernels: loads and stores
     // share one in-order counter, and a load waited for after the stores would also wait for the stores).  The text
-    // itself is only fetched -- by LDS-DMA, also one chunk ahead -- for chunks with pieces the byte-wise machine must see.
+    // itself is only fetched -- by LDS-DMA, also one chunk ahead -- for chunks with queued pieces.
     struct Fetched { uint32_t ls_flags, ls_rec_tail; uint4 p0, p1; };
     auto fetch = [&](uint32_t c, Fetched &f) {
         const LaneState l = lane_state[(uint64_t)c * WG + threadIdx.x];
@@ -308,10 +308,11 @@ __global__ __launch_bounds__(WG, PK_LB_SQ) void k_squeeze(const uint8_t *__restr
         uint8_t *piece = buf + threadIdx.x * PIECE;
         PieceBases pb;
         pb.clear();
-        // Plain sequence text: the structure pass's pack plus this lane's state.  Pieces with a header, a blank or a
-        // control byte need the byte-wise machine, which costs the same for one lane as for 64: they are queued, and the
-        // queue is worked off 64 pieces per wave pass -- with a header every kilobase (read sets) that is one pass per
-        // workgroup instead of one per wave.  A queued piece's result is left in the piece's own 64 bytes of the image.
+        // Plain sequence text: the structure pass's pack plus this lane's state.  Every other piece needs the chunk's
+        // text: header pieces take it by masks (squeeze_header_piece), pieces with a blank or control byte outside header
+        // text byte by byte, which costs the same for one lane as for 64.  They are queued, and the queue is worked off 64
+        // pieces per wave pass -- with a header every kilobase (read sets) that is one pass per workgroup instead of one
+        // per wave.  A queued piece's result is left in the piece's own 64 bytes of the image.
         const bool clean = !lane_state_dirty(lst) && !lane_state_header_piece(lst) && ls_in != LS_HEADER;   // the structure pass's definition: chunk_odd counts the rest
         {
             PiecePack pk;
