@@ -344,6 +344,22 @@ def test_read_set_headers_fuzz(gpu):
         data = b"".join(parts)
         for k in ((3, 15) if trial < 2 else (9,)):
             _check_against_oracle(gpu, data, k)
+        if trial in (1, 2):
+            # the same bytes through the streaming interface, cut at random places (inside header lines, between CR and
+            # LF, one-byte feeds): the carried parser state meets header pieces at every offset
+            k = 7
+            want = oracle.count_fasta(data, k)
+            cuts = np.unique(np.concatenate([[0, len(data)], rng.integers(0, len(data), size=40), rng.integers(0, len(data), size=5) + 1]))
+            cuts = cuts[cuts <= len(data)]
+            with gpu.Indexer(k) as ix:
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    ix.feed(data[int(a):int(b)])
+                fin = ix.finish()
+                recs = ix.records(fin["n_records"])
+                assert fin["num_kmers"] == want["num_kmers"] and fin["total_bp"] == want["total_bp"]
+                assert np.array_equal(ix.table_to_host(), want["table"])
+                for f in ("name_off", "name_len", "seq_len", "n_valid_kmers"):
+                    assert np.array_equal(recs[f], want["records"][f]), f
 
 
 def test_unwrapped_long_lines_and_empty(gpu):
