@@ -517,14 +517,18 @@ __global__ __launch_bounds__(1024) void k_level1_finish(const uint32_t *__restri
 __global__ __launch_bounds__(256) void k_tally_sum(const uint32_t *__restrict__ rows, uint32_t n_rows, uint32_t n_cols, uint32_t *__restrict__ tot) {
     const uint32_t col = blockIdx.x * 256u + threadIdx.x;
     if (col >= n_cols) return;
-    uint32_t acc[4] = {0, 0, 0, 0};
+    // sixteen rows in flight per thread: the launch is 64 workgroups of latency (256 rows -> 16 round trips instead of 64)
+    uint32_t acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t r = 0;
-    for (; r + 4 <= n_rows; r += 4) {
+    for (; r + 16 <= n_rows; r += 16) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) acc[u] += rows[(uint64_t)(r + u) * n_cols + col];
+        for (int u = 0; u < 16; u++) acc[u] += rows[(uint64_t)(r + u) * n_cols + col];
     }
     for (; r < n_rows; r++) acc[0] += rows[(uint64_t)r * n_cols + col];
-    tot[col] = acc[0] + acc[1] + acc[2] + acc[3];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int u = 0; u < 16; u++) sum += acc[u];
+    tot[col] = sum;
 }
 
 // ------------------------------------------------------------------ launchers -------------------
