@@ -288,7 +288,9 @@ def main():
         ptrs = [s.data_ptr() for s in slices]
         group = True if dist is not None else None
 
-        def timed(windows, reps=4):
+        def timed(windows, reps=8):
+            # the first launches over tables this kernel has not touched yet are slow (3.9, 2.3, 3.3 ms, then 2.25-2.29 for
+            # as long as one cares to repeat: `tools/gram_stagger.py`): one untimed call, the best of the seven behind it
             best, kern, pairs = None, None, None
             for rep in range(reps):
                 barrier()
