@@ -130,18 +130,10 @@ __device__ __forceinline__ uint32_t header_text_end(const uint8_t *text, unsigne
     return end;
 }
 
-#ifdef PK_HP_NOINLINE
-#define PK_HP_INLINE __attribute__((noinline))
-#else
-#define PK_HP_INLINE __forceinline__
-#endif
 // All lanes of the wave; `mine`: this lane holds a header piece of a live record (wq.rec != 0) in `text`, with wq at the
 // exact state of its first byte.  Leaves the piece's bases in rb and the tallies of the piece's LAST record in wq (the
 // caller flushes them); the records that end inside the piece are flushed here.
-#ifdef PK_HP_NOINLINE
-__device__ __attribute__((noinline)) void squeeze_header_piece(const uint8_t *text, SeqWalker &wq, PieceBases &rb, bool mine);
-#endif
-__device__ PK_HP_INLINE void squeeze_header_piece(const uint8_t *text, SeqWalker &wq, PieceBases &rb, bool mine) {
+__device__ __forceinline__ void squeeze_header_piece(const uint8_t *text, SeqWalker &wq, PieceBases &rb, bool mine) {
     PieceMasks pm;
     uint32_t cw[4];
     piece_scan(text, (uint32_t)PIECE, pm, cw);
@@ -335,11 +327,7 @@ __global__ __launch_bounds__(WG, PK_LB_SQ) void k_squeeze(const uint8_t *__restr
                 wq.setup(k, recs, recs_cap, &racc);
                 wq.begin(lane_state_ls(l2s), l2_compose(chunk_st, lane_state_l2(l2s), km1), stream_off + base + (uint64_t)pc * PIECE);
                 // header pieces by masks (text in front of the first record is dropped: that piece takes the byte-wise walk)
-#ifdef PK_NO_HP_MASKS
-                const bool by_masks = false;
-#else
                 const bool by_masks = work && lane_state_header_piece(l2s) && wq.rec != 0u;
-#endif
                 const uint32_t nbq = (work && !by_masks) ? piece_len_of(pc, base, n_bytes) : 0u;
                 uint8_t *pq = buf + pc * PIECE;
                 PieceBases rb;
